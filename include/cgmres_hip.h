@@ -1,0 +1,155 @@
+/* cgmres_hip.h — C ABI of libcgmres_hip.so: batched C/GMRES control ticks on MI355X (gfx950).
+ *
+ * This is the drop-in boundary for ONE path of blockahead/CGMRES_cpp: the per-tick FDGMRES solve
+ *     Cgmres<Model>::control()      reference include/cgmres.hpp:78-110
+ *       F_func / Ax_func            reference include/cgmres.hpp:113-175
+ *       Gmres::gmres()              reference include/gmres.hpp:28-112
+ * batched over `batch` independent controller instances that advance in lock-step (one shared t).
+ * The reference has no FFI; its boundary is the C++ class surface, which include/cgmres.hpp (façade)
+ * re-creates on top of the entry points below.  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative CGMRES_HIP_E* code otherwise; the message of the
+ *     last failure on the calling thread is cgmres_hip_last_error().  No exceptions cross the ABI.
+ *   - `void*` vectors hold `double` (dtype F64) or `float` (dtype F32) scalars.
+ *   - all vectors are INSTANCE-MAJOR, instance b first, then the reference's own layout:
+ *       x[b][dim_x], u[b][dim_u], U[b][dim_u*stage + j] (cgmres.hpp:13,57),
+ *       ptau[b][dim_p*stage + j], stage = 0..dv (cgmres.hpp:17,37-38).
+ *     Host entry points take host pointers; *_device entry points take device pointers with the same
+ *     layout (HBM resident: nothing crosses PCIe in them).
+ *   - one handle = one GPU + one HIP stream; a handle is not re-entrant, distinct handles are independent
+ *     (same threading contract as distinct Cgmres objects).
+ *   - there is NO CPU fallback: without a usable gfx950 device cgmres_hip_create fails.
+ */
+#ifndef CGMRES_HIP_H_
+#define CGMRES_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CGMRES_HIP_ABI_VERSION 1
+
+/* problem definitions compiled into the library (reference <example>/model.hpp) */
+enum {
+  CGMRES_HIP_MODEL_PENDULUM = 0,   /* arm_type_inverted_pendulum/model.hpp == multiple_controller/model2.hpp */
+  CGMRES_HIP_MODEL_MSD = 1,        /* mass_spring_damper/model.hpp        == multiple_controller/model1.hpp */
+  CGMRES_HIP_MODEL_SEMIACTIVE = 2, /* semiactive_damper/model.hpp */
+  CGMRES_HIP_MODEL_COUNT = 3
+};
+enum { CGMRES_HIP_F64 = 0, CGMRES_HIP_F32 = 1 };
+
+/* error codes */
+enum {
+  CGMRES_HIP_OK = 0,
+  CGMRES_HIP_EINVAL = -1,   /* bad argument / unsupported configuration */
+  CGMRES_HIP_ENODEV = -2,   /* no usable gfx950 device */
+  CGMRES_HIP_ERUNTIME = -3, /* HIP runtime error */
+  CGMRES_HIP_ENOMEM = -4
+};
+
+/* per-instance exit reason of the last solve (the reference only prints "Breakdown", gmres.hpp:64) */
+enum {
+  CGMRES_HIP_EXIT_NATURAL = 0,        /* all k_max Arnoldi iterations ran      gmres.hpp:46 */
+  CGMRES_HIP_EXIT_CONVERGED = 1,      /* |rho_e[k+1]| < tol                     gmres.hpp:93-95 */
+  CGMRES_HIP_EXIT_SMALL_RESIDUAL = 2, /* ||r0|| < tol, dUdt untouched           gmres.hpp:39-41 */
+  CGMRES_HIP_EXIT_BREAKDOWN = 3       /* |h(k+1,k)| < DBL_EPSILON, dUdt untouched  gmres.hpp:63-65 */
+};
+
+/* Run-time counterpart of the `static constexpr` block of a reference Model (e.g.
+ * arm_type_inverted_pendulum/model.hpp:7-35), which Cgmres re-exports (cgmres.hpp:179-188). */
+typedef struct cgmres_hip_config {
+  int32_t abi_version; /* CGMRES_HIP_ABI_VERSION */
+  int32_t model_id;    /* CGMRES_HIP_MODEL_* */
+  int32_t dtype;       /* CGMRES_HIP_F64 / _F32 */
+  int32_t batch;       /* number of controller instances B >= 1 */
+  int32_t dv;          /* Model::dv    horizon stages */
+  int32_t k_max;       /* Model::k_max GMRES iterations */
+  int32_t device;      /* HIP device ordinal */
+  int32_t variant;     /* kernel mapping: 0 = library default, >0 = explicit */
+  double tol;          /* Model::tol */
+  double dt;           /* Model::dt   sampling period */
+  double h;            /* Model::h    forward-difference step */
+  double zeta;         /* Model::zeta */
+  double Tf;           /* Model::Tf */
+  double alpha;        /* Model::alpha */
+  void* stream;        /* hipStream_t to launch on; NULL = the library creates its own */
+} cgmres_hip_config;
+
+typedef struct cgmres_hip_ctx* cgmres_hip_handle;
+
+/* ---- registry -------------------------------------------------------------------------------- */
+/* dims[0..4] = dim_x, dim_u, dim_p, shipped dv, shipped k_max; tuning[0..5] = dt, h, zeta, Tf, alpha, tol */
+int cgmres_hip_model_info(int32_t model_id, int32_t dims[5], double tuning[6]);
+/* Fills every field of *cfg from the registry (shipped dv / k_max / tuning), batch = 1, device = 0. */
+int cgmres_hip_default_config(int32_t model_id, cgmres_hip_config* cfg);
+/* Evaluates the DEVICE model functions at one probe point (fp64) so a host binding can fingerprint a
+ * user Model class against the registry: out = [dxdt(dim_x) | dPhidx(dim_x) | dHdx(dim_x) | dHdu(dim_u)]. */
+int cgmres_hip_model_probe(int32_t model_id, int32_t device, const double* x, const double* u, const double* p,
+                           const double* lmd, double* out);
+const char* cgmres_hip_last_error(void);
+int cgmres_hip_device_count(void);
+
+/* ---- lifetime: Cgmres() / ~Cgmres(), cgmres.hpp:11-30 ------------------------------------------- */
+/* State after create: t = 0, U = 0, dUdt = 0 (the reference leaves dUdt uninitialised, cgmres.hpp:14). */
+int cgmres_hip_create(const cgmres_hip_config* cfg, cgmres_hip_handle* out);
+int cgmres_hip_destroy(cgmres_hip_handle h);
+int cgmres_hip_get_config(cgmres_hip_handle h, cgmres_hip_config* cfg);
+
+/* ---- setup: cgmres.hpp:36-76 --------------------------------------------------------------------- */
+/* per_instance = 0: one vector broadcast to every instance; 1: [batch][...] */
+int cgmres_hip_set_ptau(cgmres_hip_handle h, const void* ptau, int per_instance);         /* cgmres.hpp:36-39 */
+int cgmres_hip_set_ptau_repeat(cgmres_hip_handle h, const void* p, int per_instance);     /* cgmres.hpp:41-49 */
+int cgmres_hip_init_u0(cgmres_hip_handle h, const void* u0, int per_instance);            /* cgmres.hpp:51-59 */
+/* Batched Newton on dH/du = 0 with the 3x3 / 6x6 partial-pivot solve (matrix.hpp:166-224), on the device.
+ * u0 [batch][dim_u] in/out, x0 [batch][dim_x], p0 [batch][dim_p] (ignored when dim_p = 0).  cgmres.hpp:61-76 */
+int cgmres_hip_init_u0_newton(cgmres_hip_handle h, void* u0, const void* x0, const void* p0, int32_t n_loop);
+
+/* ---- the hot path: Cgmres::control, cgmres.hpp:78-110 -------------------------------------------- */
+/* One tick for every instance: u [batch][dim_u] out, x [batch][dim_x] in.  Host pointers; blocks. */
+int cgmres_hip_control(cgmres_hip_handle h, void* u, const void* x);
+/* Same, device pointers, asynchronous on the handle's stream. */
+int cgmres_hip_control_device(cgmres_hip_handle h, void* u_dev, const void* x_dev);
+/* n_ticks of the example main loop (<example>/main.cpp:63-73) without leaving the GPU: control, then the
+ * simulator's forward-Euler plant step x += dxdt(x,u)*dt.  x_dev in/out, u_dev = last tick's u.
+ * Asynchronous on the handle's stream. */
+int cgmres_hip_closed_loop_device(cgmres_hip_handle h, void* x_dev, void* u_dev, int32_t n_ticks);
+int cgmres_hip_synchronize(cgmres_hip_handle h);
+
+/* ---- state: the private members of Cgmres (cgmres.hpp:195-202) and Gmres (gmres.hpp:120-124) ------ */
+int cgmres_hip_get_time(cgmres_hip_handle h, double* t);
+int cgmres_hip_get_state(cgmres_hip_handle h, double* t, void* U, void* dUdt); /* [batch][dim_u*dv]; NULL skips */
+int cgmres_hip_set_state(cgmres_hip_handle h, double t, const void* U, const void* dUdt);
+/* n_ax[b] = Arnoldi mat-vecs executed inside the k loop of the last solve, reason[b] = CGMRES_HIP_EXIT_* */
+int cgmres_hip_get_status(cgmres_hip_handle h, int32_t* n_ax, int32_t* reason);
+/* H [batch][(k_max+1)*(k_max+1)] column-major ld k_max+1 (gmres.hpp:12,54), rho [batch][k_max+1],
+ * g [batch][3*k_max] (gmres.hpp:14), V [batch][(k_max+1)*len] column-major (gmres.hpp:11); NULL skips */
+int cgmres_hip_get_krylov(cgmres_hip_handle h, void* V, void* H, void* rho, void* g);
+
+/* ---- white-box hooks used by the parity tests (private methods of the reference) ------------------ */
+/* F_func(ret, U, x, t), cgmres.hpp:113-162, with the handle's ptau.  All [batch][...], host pointers. */
+int cgmres_hip_F_func(cgmres_hip_handle h, void* ret, const void* U, const void* x, double t);
+/* The statements of control() before the solve (cgmres.hpp:83-96): leaves x_dxh, F_dxh_h in the handle and
+ * returns the GMRES right-hand side b [batch][len]. */
+int cgmres_hip_prepare(cgmres_hip_handle h, void* b, const void* x);
+/* Ax_func(out, v), cgmres.hpp:164-175; needs cgmres_hip_prepare first. */
+int cgmres_hip_Ax_func(cgmres_hip_handle h, void* out, const void* v);
+/* Gmres::gmres(x, b), gmres.hpp:28-112; needs cgmres_hip_prepare first. x [batch][len] in/out. */
+int cgmres_hip_gmres(cgmres_hip_handle h, void* x, const void* b);
+
+/* ---- measurement ---------------------------------------------------------------------------------- */
+/* HIP events on the handle's stream around whatever is enqueued between the two calls. */
+int cgmres_hip_timer_start(cgmres_hip_handle h);
+int cgmres_hip_timer_stop(cgmres_hip_handle h, float* elapsed_ms); /* synchronises the stream */
+/* Device allocator for callers without a HIP runtime of their own (tests, bench via ctypes). */
+int cgmres_hip_malloc(cgmres_hip_handle h, void** dev_ptr, uint64_t bytes);
+int cgmres_hip_free(cgmres_hip_handle h, void* dev_ptr);
+int cgmres_hip_memcpy_h2d(cgmres_hip_handle h, void* dev_dst, const void* host_src, uint64_t bytes);
+int cgmres_hip_memcpy_d2h(cgmres_hip_handle h, void* host_dst, const void* dev_src, uint64_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CGMRES_HIP_H_ */

@@ -40,7 +40,8 @@ class Controller {
       : dv_(dv), kmax_(kmax), len_(nu * dv), tol_(T(tol)), tun_(Model::tuning()),
         U_(len_, T(0)), dUdt_(len_, T(0)), Fh_(len_, T(0)), xh_(nx, T(0)), ptau_(np * (dv + 1) + 1, T(0)),
         V_(size_t(len_) * (kmax + 1), T(0)), H_(size_t(kmax + 1) * (kmax + 1), T(0)), rho_(kmax + 1, T(0)),
-        g_(3 * kmax, T(0)), scratch_(len_, T(0)), xtau_(nx * (dv + 1)), ltau_(nx * (dv + 1)) {}
+        g_(3 * kmax, T(0)), scratch_(len_, T(0)), xtau_(nx * (dv + 1)), ltau_(nx * (dv + 1)), b_(len_, T(0)),
+        ub_(len_, T(0)) {}
 
   int dv() const { return dv_; }
   int kmax() const { return kmax_; }
@@ -76,7 +77,7 @@ class Controller {
   // One control tick — cgmres.hpp:78-110
   void control(T* u, const T* x) {
     const T h = T(tun_.h), zeta = T(tun_.zeta), dt = T(tun_.dt);
-    std::vector<T> b(len_);
+    std::vector<T>& b = b_;  // the reference's stack array b_vec (cgmres.hpp:79)
     // :83-85  x_dxh = dxdt*h + x  (scale, then add: two roundings)
     Model::dxdt(xh_.data(), x, &U_[0], &ptau_[0]);
     for (int i = 0; i < nx; ++i) xh_[i] = xh_[i] * h;
@@ -124,7 +125,7 @@ class Controller {
   // Uses the state left by control(): U, x_dxh, F_dxh_h, t.
   void Ax(T* out, const T* v) {
     const T h = T(tun_.h);
-    std::vector<T> Ub(len_);
+    std::vector<T>& Ub = ub_;  // the reference's stack array U_buf (cgmres.hpp:165)
     for (int i = 0; i < len_; ++i) Ub[i] = v[i] * h;        // :168
     for (int i = 0; i < len_; ++i) Ub[i] = Ub[i] + U_[i];   // :169
     F(out, Ub.data(), xh_.data(), t_ + h);                  // :170
@@ -278,7 +279,7 @@ class Controller {
   Tuning tun_;
   T t_ = T(0);
   std::vector<T> U_, dUdt_, Fh_, xh_, ptau_;
-  std::vector<T> V_, H_, rho_, g_, scratch_, xtau_, ltau_;
+  std::vector<T> V_, H_, rho_, g_, scratch_, xtau_, ltau_, b_, ub_;
   int n_ax_ = 0, k_used_ = 0, exit_ = kExitNatural;
 };
 

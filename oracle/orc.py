@@ -53,6 +53,8 @@ def _load(path):
     lib.orc_get_krylov.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
     lib.orc_last_solve.argtypes = [C.c_void_p, _ip]
     lib.orc_plant.argtypes = [C.c_void_p, _dp, _dp, _dp]
+    lib.orc_run_closed_loop.restype = C.c_double
+    lib.orc_run_closed_loop.argtypes = [C.POINTER(C.c_void_p), C.c_int, _dp, _dp, C.c_int, C.c_int]
     return lib
 
 
@@ -261,3 +263,15 @@ def closed_loop(ctrl, x0, n_ticks, record_state=False):
         us.append(u)
         xs.append(x.copy())
     return np.array(us), np.array(xs), np.array(ks), states
+
+
+def run_closed_loop(ctrls, x, ticks, nthreads):
+    """CPU-baseline driver: `ticks` closed-loop ticks of every controller in `ctrls` (same library),
+    instances statically partitioned over `nthreads` native threads.  x [n, dim_x] is advanced in place.
+    Returns (wall seconds, u of the last tick)."""
+    n = len(ctrls)
+    hs = (C.c_void_p * n)(*[c._h for c in ctrls])
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    u = np.zeros((n, ctrls[0].dim_u))
+    secs = ctrls[0]._lib.orc_run_closed_loop(hs, n, _p(x), _p(u), int(ticks), int(nthreads))
+    return secs, u, x

@@ -43,6 +43,11 @@ void orc_last_solve(void* c, int* out);
 /* plant right-hand side of the example's simulator.hpp */
 void orc_plant(void* c, double* dxdt, const double* x, const double* u);
 
+/* CPU-baseline driver (bench.py cpu_baseline leg): `ticks` closed-loop ticks (control, then the example's
+ * forward-Euler plant step, <example>/main.cpp:66-73) of n independent controllers, statically partitioned
+ * over nthreads std::threads.  x [n][dim_x] in/out, u [n][dim_u] out (last tick).  Returns wall seconds. */
+double orc_run_closed_loop(void** ctrls, int n, double* x, double* u, int ticks, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,7 +3,10 @@
 // _ref/libref.so (unmodified reference).  A library defines `OrcBase* orc_factory(...)` and
 // includes this header with ORC_DEFINE_CAPI to get the extern "C" entry points.
 #pragma once
+#include <chrono>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 #include "orc_api.h"
 
@@ -58,5 +61,29 @@ void orc_get_krylov(void* c, double* V, double* H, double* rho, double* g) {
 }
 void orc_last_solve(void* c, int* o) { static_cast<OrcBase*>(c)->last_solve(o); }
 void orc_plant(void* c, double* f, const double* x, const double* u) { static_cast<OrcBase*>(c)->plant(f, x, u); }
+double orc_run_closed_loop(void** ctrls, int n, double* x, double* u, int ticks, int nthreads) {
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > n) nthreads = n;
+  auto work = [&](int lo, int hi) {
+    double f[16];
+    for (int i = lo; i < hi; ++i) {
+      OrcBase* c = static_cast<OrcBase*>(ctrls[i]);
+      const int nx = c->dims[0], nu = c->dims[1];
+      const double dt = c->tun[0];
+      double* xi = x + size_t(i) * nx;
+      double* ui = u + size_t(i) * nu;
+      for (int t = 0; t < ticks; ++t) {
+        c->control(ui, xi);
+        c->plant(f, xi, ui);
+        for (int k = 0; k < nx; ++k) xi[k] = xi[k] + f[k] * dt;
+      }
+    }
+  };
+  const auto t0 = std::chrono::steady_clock::now();
+  std::vector<std::thread> th;
+  for (int w = 0; w < nthreads; ++w) th.emplace_back(work, int(long(n) * w / nthreads), int(long(n) * (w + 1) / nthreads));
+  for (auto& t : th) t.join();
+  return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
 }
 #endif
