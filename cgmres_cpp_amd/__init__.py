@@ -23,7 +23,8 @@ ABI_VERSION = 1
 
 # every symbol include/cgmres_hip.h declares (tests/test_capi_symbols.py checks header == this == library)
 SYMBOLS = [
-    "cgmres_hip_model_info", "cgmres_hip_default_config", "cgmres_hip_model_probe", "cgmres_hip_last_error",
+    "cgmres_hip_model_info", "cgmres_hip_default_config", "cgmres_hip_model_probe", "cgmres_hip_selftest_sincos",
+    "cgmres_hip_last_error",
     "cgmres_hip_device_count", "cgmres_hip_create", "cgmres_hip_destroy", "cgmres_hip_get_config",
     "cgmres_hip_set_ptau", "cgmres_hip_set_ptau_repeat", "cgmres_hip_init_u0", "cgmres_hip_init_u0_newton",
     "cgmres_hip_control", "cgmres_hip_control_device", "cgmres_hip_closed_loop_device", "cgmres_hip_synchronize",
@@ -68,6 +69,8 @@ def load():
     lib.cgmres_hip_model_info.argtypes = [i32, C.POINTER(i32), C.POINTER(C.c_double)]
     lib.cgmres_hip_default_config.argtypes = [i32, C.POINTER(Config)]
     lib.cgmres_hip_model_probe.argtypes = [i32, i32] + [C.POINTER(C.c_double)] * 5
+    lib.cgmres_hip_selftest_sincos.argtypes = [i32, C.POINTER(C.c_double), i32, C.POINTER(C.c_double),
+                                               C.POINTER(C.c_double)]
     lib.cgmres_hip_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     lib.cgmres_hip_destroy.argtypes = [vp]
     lib.cgmres_hip_get_config.argtypes = [vp, C.POINTER(Config)]
@@ -128,6 +131,16 @@ def model_probe(model, x, u, p, lmd, device=0):
                                          out.ctypes.data_as(dp)))
     nx = mi["dim_x"]
     return out[:nx], out[nx:2 * nx], out[2 * nx:3 * nx], out[3 * nx:]
+
+
+def selftest_sincos(a, device=0):
+    """(sin, cos) of the fp64 arguments `a` as computed by the device routine of the horizon sweeps."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    s, c = np.empty_like(a), np.empty_like(a)
+    dp = C.POINTER(C.c_double)
+    _check(load().cgmres_hip_selftest_sincos(device, a.ctypes.data_as(dp), a.size, s.ctypes.data_as(dp),
+                                             c.ctypes.data_as(dp)))
+    return s, c
 
 
 class DeviceBuffer:
@@ -207,7 +220,9 @@ class CgmresBatch:
         h = C.c_void_p()
         _check(lib.cgmres_hip_create(C.byref(cfg), C.byref(h)))
         self._h = h.value
+        _check(lib.cgmres_hip_get_config(self._h, C.byref(cfg)))  # resolved variant
         self.cfg = cfg
+        self.variant = cfg.variant
         mi = model_info(self.model)
         self.dim_x, self.dim_u, self.dim_p = mi["dim_x"], mi["dim_u"], mi["dim_p"]
         self.batch, self.dv, self.k_max = cfg.batch, cfg.dv, cfg.k_max

@@ -1,0 +1,260 @@
+// Host side of the "wg" mapping (tick_wg.hip.h): owns the instance-major HBM state of the batch,
+// computes the batch-wide scalars of each tick (t, dtau) and launches one kernel per control tick.
+#pragma once
+#include "ctx_common.hip.h"
+#include "tick_wg.hip.h"
+#include "util_kernels.hip.h"
+
+namespace cgm {
+
+constexpr size_t kLdsLimit = 160 * 1024;  // gfx950: 160 KiB per workgroup
+
+template <class T>
+__global__ void replicate_rows_im(T* __restrict__ dst, size_t dst_pitch, const T* __restrict__ src, int B, int n,
+                                  int reps, int bcast) {
+  // dst[b][rep*n + j] = src[(bcast ? 0 : b)*n + j]
+  const int b = blockIdx.y;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < n * reps; q += gridDim.x * blockDim.x)
+    if (b < B) dst[size_t(b) * dst_pitch + q] = src[size_t(bcast ? 0 : b) * n + (q % n)];
+}
+
+template <class M, class T>
+struct CtxWg final : cgmres_hip_ctx {
+  WgParams<T> P{};
+  T t = T(0);
+  int ipw = 0, maxm = 0, ks_all = 0;
+  size_t lds_bytes = 0;
+  void (*k_tick)(WgParams<T>) = nullptr;
+  void (*k_hook)(WgParams<T>) = nullptr;
+  T *stage = nullptr, *stage2 = nullptr;
+  size_t stage_n = 0, stage2_n = 0;
+  T *x_dev = nullptr, *u_dev = nullptr;
+
+  const char* variant_name() const override { return "wg"; }
+
+  // (IPW, MAXM) instantiations: 16 or 8 instances per workgroup, vectors up to 160 or 320 elements
+  template <int IPW, int MAXM>
+  void pick() {
+    k_tick = tick_wg_kernel<M, T, IPW, MAXM>;
+    k_hook = hook_wg_kernel<M, T, IPW, MAXM>;
+    ipw = IPW, maxm = MAXM;
+  }
+  static bool supported(const cgmres_hip_config& c, int* ipw_out, size_t* bytes_out) {
+    const int L = M::NU * c.dv;
+    if (L > 320) return false;
+    const int Lp = L | 1, Pp = (M::NP * (c.dv + 1)) | 1, Hp = ((c.k_max + 1) * (c.k_max + 1)) | 1;
+    const size_t b16 = WgLds<M, T, 16>::bytes(c.dv, c.k_max, Lp, Pp, Hp);
+    const size_t b8 = WgLds<M, T, 8>::bytes(c.dv, c.k_max, Lp, Pp, Hp);
+    if (b16 <= kLdsLimit) {
+      *ipw_out = 16, *bytes_out = b16;
+      return true;
+    }
+    if (b8 <= kLdsLimit) {
+      *ipw_out = 8, *bytes_out = b8;
+      return true;
+    }
+    return false;
+  }
+
+  int init() override {
+    if (int rc = init_common()) return rc;
+    nx = M::NX, nu = M::NU, np = M::NP;
+    L = nu * cfg.dv;
+    int want = 0;
+    if (!supported(cfg, &want, &lds_bytes))
+      return fail(CGMRES_HIP_EINVAL, "wg mapping: dim_u*dv = %d / LDS footprint not supported", L);
+    const bool big = L > 160;
+    if (want == 16 && !big) pick<16, 10>();
+    if (want == 16 && big) pick<16, 20>();
+    if (want == 8 && !big) pick<8, 10>();
+    if (want == 8 && big) pick<8, 20>();
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                int(lds_bytes)));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hook), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                int(lds_bytes)));
+    const int k1 = cfg.k_max + 1;
+    ks_all = k1 * k1 + k1 + 3 * cfg.k_max;
+    P.B = cfg.batch, P.dv = cfg.dv, P.kmax = cfg.k_max, P.L = L;
+    P.Lp = L | 1, P.Lg = (L + 15) / 16 * 16, P.Pp = (np * (cfg.dv + 1)) | 1, P.Hp = (k1 * k1) | 1;
+    P.h = T(cfg.h), P.dt = T(cfg.dt), P.tol = T(cfg.tol);
+    P.inv_h = T(1.0) / P.h;
+    P.one_m_zh = (1 - T(cfg.zeta) * P.h);
+    const size_t B = cfg.batch, Lg = P.Lg;
+    int rc = 0;
+    if ((rc = dalloc(&P.U, B * Lg)) || (rc = dalloc(&P.dUdt, B * Lg)) || (rc = dalloc(&P.Fh, B * Lg)) ||
+        (rc = dalloc(&P.V, B * k1 * Lg)) || (rc = dalloc(&P.xdxh, B * nx)) ||
+        (rc = dalloc(&P.ptau, B * size_t(np) * (cfg.dv + 1))) || (rc = dalloc(&P.kry, B * ks_all)) ||
+        (rc = dalloc(&P.n_ax, B)) || (rc = dalloc(&P.reason, B)) || (rc = dalloc(&x_dev, B * nx)) ||
+        (rc = dalloc(&u_dev, B * nu)))
+      return rc;
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+  }
+
+  dim3 grid() const { return dim3((cfg.batch + ipw - 1) / ipw); }
+  dim3 block() const { return dim3(ipw * 16); }
+  T dtau_of(T tt) const {  // cgmres.hpp:32-34, once per tick on the host for the whole batch
+    return T(cfg.Tf) * (1 - std::exp(-T(cfg.alpha) * tt)) / T(cfg.dv);
+  }
+
+  // host [B][n] <-> device rows with pitch
+  int rows_h2d(T* dst, size_t pitch, const void* src, int n) {
+    HIP_TRY(hipMemcpy2DAsync(dst, pitch * sizeof(T), src, size_t(n) * sizeof(T), size_t(n) * sizeof(T), cfg.batch,
+                             hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+  }
+  int rows_d2h(void* dst, const T* src, size_t pitch, int n, size_t rows) {
+    if (!dst) return 0;
+    HIP_TRY(hipMemcpy2DAsync(dst, size_t(n) * sizeof(T), src, pitch * sizeof(T), size_t(n) * sizeof(T), rows,
+                             hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+  }
+  int replicate(T* dst, size_t pitch, const void* src, int n, int reps, int per_instance) {
+    const size_t cnt = size_t(per_instance ? cfg.batch : 1) * n;
+    if (int rc = grow(&stage, &stage_n, cnt)) return rc;
+    HIP_TRY(hipMemcpyAsync(stage, src, cnt * sizeof(T), hipMemcpyHostToDevice, stream));
+    replicate_rows_im<T><<<dim3(4, cfg.batch), 256, 0, stream>>>(dst, pitch, stage, cfg.batch, n, reps, !per_instance);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+  }
+
+  int set_ptau(const void* p, int per_instance, bool repeat) override {
+    HIP_TRY(hipSetDevice(cfg.device));
+    if (np == 0) return 0;
+    if (!p) return fail(CGMRES_HIP_EINVAL, "set_ptau: null pointer");
+    const int all = np * (cfg.dv + 1);
+    return repeat ? replicate(P.ptau, all, p, np, cfg.dv + 1, per_instance) : replicate(P.ptau, all, p, all, 1, per_instance);
+  }
+  int init_u0(const void* u0, int per_instance) override {
+    HIP_TRY(hipSetDevice(cfg.device));
+    if (!u0) return fail(CGMRES_HIP_EINVAL, "init_u0: null pointer");
+    return replicate(P.U, P.Lg, u0, nu, cfg.dv, per_instance);
+  }
+  int init_u0_newton(void* u0, const void* x0, const void* p0, int n_loop) override {
+    HIP_TRY(hipSetDevice(cfg.device));
+    if (!u0 || !x0 || (np && !p0)) return fail(CGMRES_HIP_EINVAL, "init_u0_newton: null pointer");
+    if (n_loop < 0) return fail(CGMRES_HIP_EINVAL, "init_u0_newton: n_loop < 0");
+    const size_t B = cfg.batch;
+    if (int rc = grow(&stage2, &stage2_n, B * (nu + nx + np))) return rc;
+    T *du = stage2, *dx = du + B * nu, *dp = dx + B * nx;
+    HIP_TRY(hipMemcpyAsync(du, u0, B * nu * sizeof(T), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(dx, x0, B * nx * sizeof(T), hipMemcpyHostToDevice, stream));
+    if (np) HIP_TRY(hipMemcpyAsync(dp, p0, B * np * sizeof(T), hipMemcpyHostToDevice, stream));
+    newton_u0_kernel<M, T><<<dim3((B + 63) / 64), 64, 0, stream>>>(du, dx, dp, cfg.batch, n_loop);
+    HIP_TRY(hipGetLastError());
+    replicate_rows_im<T><<<dim3(4, cfg.batch), 256, 0, stream>>>(P.U, P.Lg, du, cfg.batch, nu, cfg.dv, 0);  // cgmres.hpp:75
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(u0, du, B * nu * sizeof(T), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+  }
+
+  int launch_tick(T* u_out, const T* x_in, T* x_next) {
+    P.mode = WG_TICK;
+    P.x_in = x_in, P.u_out = u_out, P.x_next = x_next;
+    P.dtau_h = dtau_of(t + P.h);  // cgmres.hpp:88
+    P.dtau_0 = dtau_of(t);        // cgmres.hpp:91
+    k_tick<<<grid(), block(), lds_bytes, stream>>>(P);
+    HIP_TRY(hipGetLastError());
+    t = t + P.dt;  // cgmres.hpp:107
+    return 0;
+  }
+  int control_device(void* u, const void* x, void* x_next) override {
+    HIP_TRY(hipSetDevice(cfg.device));
+    if (!u || !x) return fail(CGMRES_HIP_EINVAL, "control: null pointer");
+    return launch_tick(static_cast<T*>(u), static_cast<const T*>(x), static_cast<T*>(x_next));
+  }
+  int control_host(void* u, const void* x) override {
+    HIP_TRY(hipSetDevice(cfg.device));
+    if (!u || !x) return fail(CGMRES_HIP_EINVAL, "control: null pointer");
+    HIP_TRY(hipMemcpyAsync(x_dev, x, size_t(cfg.batch) * nx * sizeof(T), hipMemcpyHostToDevice, stream));
+    if (int rc = launch_tick(u_dev, x_dev, nullptr)) return rc;
+    HIP_TRY(hipMemcpyAsync(u, u_dev, size_t(cfg.batch) * nu * sizeof(T), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+  }
+  int closed_loop(void* x, void* u, int n_ticks) override {
+    HIP_TRY(hipSetDevice(cfg.device));
+    if (!u || !x) return fail(CGMRES_HIP_EINVAL, "closed_loop: null pointer");
+    for (int i = 0; i < n_ticks; ++i)
+      if (int rc = launch_tick(static_cast<T*>(u), static_cast<const T*>(x), static_cast<T*>(x))) return rc;
+    return 0;
+  }
+
+  double time() const override { return double(t); }
+  int get_state(double* tt, void* U, void* dUdt) override {
+    HIP_TRY(hipSetDevice(cfg.device));
+    if (tt) *tt = double(t);
+    if (int rc = rows_d2h(U, P.U, P.Lg, L, cfg.batch)) return rc;
+    return rows_d2h(dUdt, P.dUdt, P.Lg, L, cfg.batch);
+  }
+  int set_state(double tt, const void* U, const void* dUdt) override {
+    HIP_TRY(hipSetDevice(cfg.device));
+    t = T(tt);
+    if (U)
+      if (int rc = rows_h2d(P.U, P.Lg, U, L)) return rc;
+    if (dUdt)
+      if (int rc = rows_h2d(P.dUdt, P.Lg, dUdt, L)) return rc;
+    return 0;
+  }
+  int get_status(int32_t* n_ax, int32_t* reason) override {
+    HIP_TRY(hipSetDevice(cfg.device));
+    if (n_ax) HIP_TRY(hipMemcpyAsync(n_ax, P.n_ax, size_t(cfg.batch) * 4, hipMemcpyDeviceToHost, stream));
+    if (reason) HIP_TRY(hipMemcpyAsync(reason, P.reason, size_t(cfg.batch) * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+  }
+  int get_krylov(void* V, void* H, void* rho, void* g) override {
+    HIP_TRY(hipSetDevice(cfg.device));
+    const int k1 = cfg.k_max + 1;
+    if (int rc = rows_d2h(V, P.V, P.Lg, L, size_t(cfg.batch) * k1)) return rc;
+    if (H)
+      if (int rc = rows_d2h(H, P.kry, ks_all, k1 * k1, cfg.batch)) return rc;
+    if (rho)
+      if (int rc = rows_d2h(rho, P.kry + k1 * k1, ks_all, k1, cfg.batch)) return rc;
+    if (g)
+      if (int rc = rows_d2h(g, P.kry + k1 * k1 + k1, ks_all, 3 * cfg.k_max, cfg.batch)) return rc;
+    return 0;
+  }
+
+  // ---- white-box hooks: same device functions, selected by P.mode ---------------------------------
+  int run_hook(int mode, const void* in0, const void* in1, void* out, const void* x, T dtau) {
+    const size_t n = size_t(cfg.batch) * L;
+    if (int rc = grow(&stage2, &stage2_n, 3 * n)) return rc;
+    T *d0 = stage2, *d1 = stage2 + n, *dout = stage2 + 2 * n;
+    if (in0) HIP_TRY(hipMemcpyAsync(d0, in0, n * sizeof(T), hipMemcpyHostToDevice, stream));
+    if (in1) HIP_TRY(hipMemcpyAsync(d1, in1, n * sizeof(T), hipMemcpyHostToDevice, stream));
+    if (x) HIP_TRY(hipMemcpyAsync(x_dev, x, size_t(cfg.batch) * nx * sizeof(T), hipMemcpyHostToDevice, stream));
+    P.mode = mode;
+    P.hook_in0 = d0, P.hook_in1 = d1, P.hook_out = out ? dout : nullptr, P.hook_dtau = dtau;
+    P.x_in = x ? x_dev : nullptr, P.u_out = nullptr, P.x_next = nullptr;
+    P.dtau_h = dtau_of(t + P.h);
+    P.dtau_0 = dtau_of(t);
+    k_hook<<<grid(), block(), lds_bytes, stream>>>(P);
+    HIP_TRY(hipGetLastError());
+    if (out) HIP_TRY(hipMemcpyAsync(out, dout, n * sizeof(T), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return 0;
+  }
+  int hook_F(void* ret, const void* U, const void* x, double tt) override {
+    HIP_TRY(hipSetDevice(cfg.device));
+    return run_hook(WG_HOOK_F, U, nullptr, ret, x, dtau_of(T(tt)));
+  }
+  int hook_prepare(void* b, const void* x) override {
+    HIP_TRY(hipSetDevice(cfg.device));
+    return run_hook(WG_HOOK_PREPARE, nullptr, nullptr, b, x, T(0));
+  }
+  int hook_Ax(void* out, const void* v) override {
+    HIP_TRY(hipSetDevice(cfg.device));
+    return run_hook(WG_HOOK_AX, v, nullptr, out, nullptr, T(0));
+  }
+  int hook_gmres(void* x, const void* b) override {
+    HIP_TRY(hipSetDevice(cfg.device));
+    return run_hook(WG_HOOK_GMRES, x, b, x, nullptr, T(0));
+  }
+};
+
+}  // namespace cgm

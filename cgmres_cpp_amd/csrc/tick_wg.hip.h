@@ -1,0 +1,592 @@
+// Variant 2 ("wg"): one workgroup owns IPW controller instances for a whole control tick.
+//
+// Mapping (gfx950, wave64):
+//   * block = IPW*16 threads; thread (inst = tid/16, r = tid%16).  The 16 lanes of one DPP row own the
+//     length-L vectors of one instance, lane r holding elements e = r + 16*m (m < MAXM) in registers.
+//     Dot products / norms are lane partial sums + a 4-step DPP butterfly inside the row
+//     (quad_perm, quad_perm, row_half_mirror, row_mirror): every lane of the row ends with the
+//     bit-identical sum, so row-uniform branches (early exit, breakdown) never diverge inside a row.
+//   * the horizon sweeps (F_func) are serial in the stage index, so they run one lane per instance
+//     on lanes 0..IPW-1 of wave 0, with U, F(U,x+hf,t+h), the work vector, the state trajectory, the
+//     reusable trig values and ptau all staged in LDS (odd row pitches: conflict-free for the
+//     16 sweep lanes).  No HBM access inside the stage loops.
+//   * the Krylov basis V (IPW x (k_max+1) x L) does not fit in 160 KB of LDS at IPW = 16, it lives in
+//     HBM/L2 as instance-major rows (each row-load is one 128-byte segment per 16 lanes) and is
+//     streamed once per Gram-Schmidt step — exactly the traffic SURVEY.md §8(d) prices.
+//   * instances never exchange data: the only synchronisation is the workgroup barrier between
+//     the sweep phase and the vector phase.
+// Statement order inside each instance follows cgmres.hpp:78-175 / gmres.hpp:28-112; what differs
+// from the reference is the association order of the length-L sums (16 partial sums + butterfly).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+
+#include "models.hip.h"
+#include "tick_lane.hip.h"  // sqrt_t / abs_t / FOut
+
+namespace cgm {
+
+enum WgMode { WG_TICK = 0, WG_HOOK_F = 1, WG_HOOK_PREPARE = 2, WG_HOOK_AX = 3, WG_HOOK_GMRES = 4 };
+
+template <class T>
+struct WgParams {
+  int B, dv, kmax, L, Lp, Lg, Pp, Hp;  // Lp/Pp/Hp: odd LDS row pitches; Lg: global row pitch (multiple of 16)
+  T h, dt, tol, inv_h, one_m_zh, dtau_h, dtau_0;
+  // instance-major HBM state
+  T *U, *dUdt, *Fh, *V, *xdxh, *ptau;  // [B][Lg], [B][Lg], [B][Lg], [B][kmax+1][Lg], [B][NX], [B][NP*(dv+1)]
+  T* kry;                              // [B][KS]: H (k1*k1 col-major) | rho (k1) | g (3*kmax)
+  int *n_ax, *reason;
+  const T* x_in;  // [B][NX]
+  T* u_out;       // [B][NU]
+  T* x_next;      // [B][NX] or null
+  // hooks
+  int mode;
+  const T *hook_in0, *hook_in1;  // instance-major [B][L]
+  T* hook_out;
+  T hook_dtau;
+};
+
+// ---- DPP row reductions -------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float x) {
+  int v = __float_as_int(x);
+  v = __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+  return __int_as_float(v);
+}
+// Sum over the 16 lanes of a DPP row; every lane receives the same bits (each step adds the two
+// operands of a commutative pair).
+template <class T>
+__device__ __forceinline__ T row16_sum(T x) {
+  x += dpp_move<0xB1>(x);   // quad_perm [1,0,3,2]
+  x += dpp_move<0x4E>(x);   // quad_perm [2,3,0,1]
+  x += dpp_move<0x141>(x);  // row_half_mirror
+  x += dpp_move<0x140>(x);  // row_mirror
+  return x;
+}
+
+// ---- LDS carve-up -------------------------------------------------------------------------------
+template <class M, class T, int IPW>
+struct WgLds {
+  T *U, *Fh, *W, *traj, *trig, *p, *H, *rho, *g, *xs, *xh;
+  int *flag, *reason, *nax, *ksolve;
+  static __host__ __device__ size_t count_T(int dv, int kmax, int Lp, int Pp, int Hp) {
+    const int k1 = kmax + 1;
+    return size_t(3) * IPW * Lp + size_t(dv) * (M::NX + M::NC) * IPW + size_t(IPW) * Pp + size_t(IPW) * Hp +
+           size_t(IPW) * k1 + size_t(IPW) * 3 * kmax + size_t(2) * M::NX * IPW;
+  }
+  static __host__ __device__ size_t bytes(int dv, int kmax, int Lp, int Pp, int Hp) {
+    return count_T(dv, kmax, Lp, Pp, Hp) * sizeof(T) + 4 * IPW * sizeof(int) + 16;
+  }
+  __device__ WgLds(unsigned char* base, const WgParams<T>& P) {
+    T* q = reinterpret_cast<T*>(base);
+    const int k1 = P.kmax + 1;
+    U = q, q += IPW * P.Lp;
+    Fh = q, q += IPW * P.Lp;
+    W = q, q += IPW * P.Lp;
+    traj = q, q += P.dv * M::NX * IPW;
+    trig = q, q += P.dv * M::NC * IPW;
+    p = q, q += IPW * P.Pp;
+    H = q, q += IPW * P.Hp;
+    rho = q, q += IPW * k1;
+    g = q, q += IPW * 3 * P.kmax;
+    xs = q, q += M::NX * IPW;
+    xh = q, q += M::NX * IPW;
+    int* z = reinterpret_cast<int*>(q);
+    flag = z, reason = z + IPW, nax = z + 2 * IPW, ksolve = z + 3 * IPW;
+  }
+};
+
+// ---- horizon sweep on LDS, one lane per instance (cgmres.hpp:113-162, :168-174) -------------------
+//   MODE F_PLAIN: out = F            F_RHS: out = (F*(1-zeta h) - Fh)/h          F_AX: out = (F - Fh)/h
+//   PERT: u = U + h*W (W is both the direction v and, afterwards, the output when `out` aliases it:
+//   stage s of `out` is written after the last read of W[s], so in-place is safe).
+template <class M, class T, int IPW, bool PERT, int MODE>
+__device__ __forceinline__ void f_eval_lds(const WgParams<T>& P, const WgLds<M, T, IPW>& S, int i, const T* x0,
+                                           T dtau, T* out) {
+  constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC;
+  const T* __restrict__ U = S.U + i * P.Lp;
+  const T* W = S.W + i * P.Lp;  // may alias `out` (in-place Ax)
+  const T* __restrict__ Fh = S.Fh + i * P.Lp;
+  const T* __restrict__ pt = S.p + i * P.Pp;
+  T* __restrict__ traj = S.traj + i;
+  T* __restrict__ trig = S.trig + i;
+  const int dv = P.dv;
+  T xs[NX];
+#pragma unroll
+  for (int c = 0; c < NX; ++c) xs[c] = x0[c];
+  for (int s = 0; s < dv; ++s) {  // cgmres.hpp:133-140
+    T u[M::NU_DYN], f[NX], tr[NC > 0 ? NC : 1];
+#pragma unroll
+    for (int j = 0; j < M::NU_DYN; ++j) {
+      T uj = U[s * NU + j];
+      if (PERT) uj = W[s * NU + j] * P.h + uj;
+      u[j] = uj;
+    }
+#pragma unroll
+    for (int c = 0; c < NX; ++c) traj[(s * NX + c) * IPW] = xs[c];
+    M::dxdt(f, xs, u, tr);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) trig[(s * NC + c) * IPW] = tr[c];
+#pragma unroll
+    for (int c = 0; c < NX; ++c) xs[c] = f[c] * dtau + xs[c];
+  }
+  T l[NX], p[NP > 0 ? NP : 1];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) p[j] = pt[dv * NP + j];
+  M::dPhidx(l, xs, p);  // cgmres.hpp:145
+  for (int s = dv - 1; s >= 0; --s) {  // cgmres.hpp:146-161
+    T u[NU], tr[NC > 0 ? NC : 1], Fs[NU], gx[NX];
+#pragma unroll
+    for (int c = 0; c < NX; ++c) xs[c] = traj[(s * NX + c) * IPW];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) tr[c] = trig[(s * NC + c) * IPW];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+      T uj = U[s * NU + j];
+      if (PERT) uj = W[s * NU + j] * P.h + uj;
+      u[j] = uj;
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) p[j] = pt[s * NP + j];
+    M::dHdu(Fs, xs, u, p, l, tr);
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+      T rj = Fs[j];
+      if (MODE == F_RHS) rj = (rj * P.one_m_zh - Fh[s * NU + j]) * P.inv_h;
+      if (MODE == F_AX) rj = (rj - Fh[s * NU + j]) * P.inv_h;
+      out[s * NU + j] = rj;
+    }
+    M::dHdx(gx, xs, u, p, l, tr);
+#pragma unroll
+    for (int c = 0; c < NX; ++c) l[c] = gx[c] * dtau + l[c];
+  }
+}
+
+// Per-thread view of one workgroup's job.
+template <class M, class T, int IPW, int MAXM>
+struct WgCtx {
+  const WgParams<T>& P;
+  WgLds<M, T, IPW> S;
+  int tid, inst, r, b;  // b = global instance of this thread's row
+  bool valid;           // row has a real instance
+  bool sweep_lane;      // this thread runs horizon sweeps (for instance `tid`)
+  int bi;               // global instance of the sweep lane
+  __device__ WgCtx(const WgParams<T>& P_, unsigned char* smem)
+      : P(P_), S(smem, P_), tid(threadIdx.x), inst(threadIdx.x >> 4), r(threadIdx.x & 15) {
+    b = blockIdx.x * IPW + inst;
+    valid = b < P.B;
+    bi = blockIdx.x * IPW + tid;
+    sweep_lane = tid < IPW && bi < P.B;
+  }
+  __device__ __forceinline__ int elem(int m) const { return r + 16 * m; }
+
+  // rows: HBM [B][Lg] -> LDS row / registers
+  __device__ __forceinline__ void load_row_to_lds(T* lds, const T* g) const {
+    if (!valid) return;
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+      const int e = elem(m);
+      if (e < P.L) lds[inst * P.Lp + e] = g[size_t(b) * P.Lg + e];
+    }
+  }
+  __device__ __forceinline__ void load_row_to_reg(T* reg, const T* g, size_t pitch) const {
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+      const int e = elem(m);
+      reg[m] = (valid && e < P.L) ? g[size_t(b) * pitch + e] : T(0);
+    }
+  }
+  __device__ __forceinline__ void lds_to_reg(T* reg, const T* lds) const {
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+      const int e = elem(m);
+      reg[m] = (e < P.L) ? lds[inst * P.Lp + e] : T(0);
+    }
+  }
+  __device__ __forceinline__ void reg_to_lds(T* lds, const T* reg) const {
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+      const int e = elem(m);
+      if (e < P.L) lds[inst * P.Lp + e] = reg[m];
+    }
+  }
+  __device__ __forceinline__ void reg_to_row(T* g, size_t pitch, const T* reg) const {
+    if (!valid) return;
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+      const int e = elem(m);
+      if (e < P.L) g[size_t(b) * pitch + e] = reg[m];
+    }
+  }
+  __device__ __forceinline__ T* vrow(int j) const {  // Krylov vector j of this row's instance
+    return P.V + (size_t(b) * (P.kmax + 1) + j) * P.Lg;
+  }
+  __device__ __forceinline__ void load_vec(T* reg, const T* row) const {
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+      const int e = elem(m);
+      reg[m] = (e < P.L) ? row[e] : T(0);
+    }
+  }
+  __device__ __forceinline__ void store_vec(T* row, const T* reg) const {
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+      const int e = elem(m);
+      if (e < P.L) row[e] = reg[m];
+    }
+  }
+
+  // Common prologue: U, ptau -> LDS; x -> LDS (component-major); flags cleared.
+  __device__ __forceinline__ void load_common(const T* Ug) {
+    load_row_to_lds(S.U, Ug);
+    if (valid) {
+      const int np_all = M::NP * (P.dv + 1);
+      for (int q = r; q < np_all; q += 16) S.p[inst * P.Pp + q] = P.ptau[size_t(b) * np_all + q];
+      if (r < M::NX) S.xs[r * IPW + inst] = P.x_in ? P.x_in[size_t(b) * M::NX + r] : T(0);
+    }
+    if (r == 0) {
+      S.flag[inst] = 0;
+      S.reason[inst] = 0;
+      S.nax[inst] = 0;
+      S.ksolve[inst] = 0;
+    }
+  }
+
+  // cgmres.hpp:83-96 on the sweep lanes: x_dxh, Fh = F(U, x_dxh, t+h), W = b.
+  __device__ __forceinline__ void preamble_sweeps() {
+    if (!sweep_lane) return;
+    constexpr int NX = M::NX;
+    const int i = tid;
+    T x[NX], u0[M::NU], f[NX], xh[NX], tr[M::NC > 0 ? M::NC : 1];
+#pragma unroll
+    for (int c = 0; c < NX; ++c) x[c] = S.xs[c * IPW + i];
+#pragma unroll
+    for (int j = 0; j < M::NU; ++j) u0[j] = S.U[i * P.Lp + j];
+    M::dxdt(f, x, u0, tr);
+#pragma unroll
+    for (int c = 0; c < NX; ++c) {
+      xh[c] = f[c] * P.h + x[c];
+      S.xh[c * IPW + i] = xh[c];
+    }
+    f_eval_lds<M, T, IPW, false, F_PLAIN>(P, S, i, xh, P.dtau_h, S.Fh + i * P.Lp);
+    f_eval_lds<M, T, IPW, false, F_RHS>(P, S, i, x, P.dtau_0, S.W + i * P.Lp);
+  }
+  // Ax_func in place on W for the sweep lanes whose instance is active (cgmres.hpp:164-175)
+  __device__ __forceinline__ void ax_sweep(bool only_active) {
+    if (!sweep_lane) return;
+    const int i = tid;
+    if (only_active && !S.flag[i]) return;
+    T xh[M::NX];
+#pragma unroll
+    for (int c = 0; c < M::NX; ++c) xh[c] = S.xh[c * IPW + i];
+    f_eval_lds<M, T, IPW, true, F_AX>(P, S, i, xh, P.dtau_h, S.W + i * P.Lp);
+  }
+
+  // Gmres::gmres (gmres.hpp:28-112).  In: x (registers `xv`), b (registers `bb`), W = A*x0 already in LDS.
+  // Out: xv updated.  All threads of the block must call this (it contains workgroup barriers).
+  __device__ __forceinline__ void gmres(T* xv, const T* bb) {
+    const int L = P.L, kmax = P.kmax, k1 = kmax + 1;
+    T* Hi = S.H + inst * P.Hp;
+    T* rhoi = S.rho + inst * k1;
+    T* gi = S.g + inst * 3 * kmax;
+    T vcur[MAXM], w[MAXM];
+    bool active = valid;
+    // r0 = b - A x0 ; rho = ||r0||      gmres.hpp:33-37
+    {
+      T ax[MAXM];
+      lds_to_reg(ax, S.W);
+      T ss = 0;
+#pragma unroll
+      for (int m = 0; m < MAXM; ++m) {
+        vcur[m] = bb[m] - ax[m];
+        ss += vcur[m] * vcur[m];
+      }
+      const T rho0 = sqrt_t<T>(row16_sum(ss));
+      if (r == 0) rhoi[0] = rho0;
+      if (active && rho0 < P.tol) {  // gmres.hpp:39-41
+        active = false;
+        if (r == 0) S.reason[inst] = 2;
+      }
+      if (active) {
+        const T inv = T(1.0) / rho0;  // gmres.hpp:44
+#pragma unroll
+        for (int m = 0; m < MAXM; ++m) vcur[m] = vcur[m] * inv;
+        store_vec(vrow(0), vcur);
+        reg_to_lds(S.W, vcur);
+      }
+      if (r == 0) S.flag[inst] = active ? 1 : 0;
+    }
+    int k = 0;
+    for (; k < kmax; ++k) {  // gmres.hpp:46
+      if (!__syncthreads_or(active ? 1 : 0)) break;  // also publishes W / flag to the sweep lanes
+      ax_sweep(true);                                // :48  W <- A v_k, in place
+      __syncthreads();
+      if (active) {
+        lds_to_reg(w, S.W);
+        T* Hk = Hi + k1 * k;
+        // modified Gram-Schmidt, gmres.hpp:52-58 — v_k is still in registers, older vectors stream from HBM/L2
+        T vi[MAXM];
+        if (k == 0) {
+#pragma unroll
+          for (int m = 0; m < MAXM; ++m) vi[m] = vcur[m];
+        } else {
+          load_vec(vi, vrow(0));
+        }
+        for (int i = 0; i <= k; ++i) {
+          T vn[MAXM];
+          if (i + 1 < k) {
+            load_vec(vn, vrow(i + 1));
+          } else {
+#pragma unroll
+            for (int m = 0; m < MAXM; ++m) vn[m] = vcur[m];
+          }
+          T part = 0;
+#pragma unroll
+          for (int m = 0; m < MAXM; ++m) part += vi[m] * w[m];
+          const T hik = row16_sum(part);
+#pragma unroll
+          for (int m = 0; m < MAXM; ++m) w[m] = w[m] - vi[m] * hik;
+          if (r == 0) Hk[i] = hik;
+#pragma unroll
+          for (int m = 0; m < MAXM; ++m) vi[m] = vn[m];
+        }
+        T nn = 0;
+#pragma unroll
+        for (int m = 0; m < MAXM; ++m) nn += w[m] * w[m];
+        const T hn = sqrt_t<T>(row16_sum(nn));  // :60
+        if (r == 0) {
+          Hk[k + 1] = hn;
+          S.nax[inst] = k + 1;
+        }
+        if (abs_t(hn) < T(DBL_EPSILON)) {  // :63-65 breakdown: x untouched
+          active = false;
+          if (r == 0) {
+            S.reason[inst] = 3;
+            S.flag[inst] = 0;
+          }
+        } else {
+          const T inv = T(1.0) / hn;  // :67
+#pragma unroll
+          for (int m = 0; m < MAXM; ++m) vcur[m] = w[m] * inv;
+          store_vec(vrow(k + 1), vcur);
+          reg_to_lds(S.W, vcur);
+          // Hessenberg column k: stored reflectors, new reflector, residual rotation (:71-90) — scalar work.
+          // Every lane of the row computes it from the same LDS words (broadcast reads; a row never straddles
+          // a wave, and LDS operations of one wave complete in order), lane 0 writes back: the convergence
+          // decision is therefore row-uniform.
+          T en;
+          {
+            for (int i = 0; i < k; ++i) {
+              const T g0 = gi[3 * i], g1 = gi[3 * i + 1], g2 = gi[3 * i + 2];
+              const T a = Hk[i], c = Hk[i + 1];
+              const T beta = (g0 * a + g1 * c) * g2;
+              if (r == 0) {
+                Hk[i] = a - beta * g0;
+                Hk[i + 1] = c - beta * g1;
+              }
+            }
+            const T a = Hk[k], c = Hk[k + 1];
+            const T sigma = -(a < T(0.0) ? T(-1.0) : T(1.0)) * sqrt_t<T>(a * a + c * c);
+            const T g0 = a - sigma, g1 = c;
+            const T g2 = T(2.0) / (g0 * g0 + g1 * g1);
+            const T ek = rhoi[k];
+            const T beta = g0 * ek * g2;
+            en = -beta * g1;
+            if (r == 0) {
+              gi[3 * k] = g0, gi[3 * k + 1] = g1, gi[3 * k + 2] = g2;
+              Hk[k] = sigma;
+              Hk[k + 1] = T(0.0);
+              rhoi[k] = ek - beta * g0;
+              rhoi[k + 1] = en;
+            }
+          }
+          if (abs_t(en) < P.tol) {  // :93-95 — converged: column k is NOT used by the solve
+            active = false;
+            if (r == 0) {
+              S.reason[inst] = 1;
+              S.ksolve[inst] = k;
+              S.flag[inst] = 0;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // natural exit: every column is used
+    const int reason = S.reason[inst];
+    const int ks = reason == 0 ? (valid ? kmax : 0) : (reason == 1 ? S.ksolve[inst] : 0);
+    if (valid && reason <= 1) {
+      // back substitution (gmres.hpp:100-107): lane 0 of the row, in LDS
+      if (r == 0) {
+        for (int i = ks - 1; i >= 0; --i) {
+          T ei = rhoi[i];
+          for (int j = ks - 1; j > i; --j) ei -= Hi[k1 * j + i] * rhoi[j];
+          rhoi[i] = ei / Hi[k1 * i + i];
+        }
+        S.ksolve[inst] = ks;
+      }
+    }
+    __syncthreads();
+    if (valid && reason <= 1) {
+      // x += V[:,0:ks] y  (gmres.hpp:110-111), accumulated j-ascending from 0 like matrix.hpp:82-91
+      T acc[MAXM];
+#pragma unroll
+      for (int m = 0; m < MAXM; ++m) acc[m] = T(0.0);
+      for (int j = 0; j < ks; ++j) {
+        T vj[MAXM];
+        load_vec(vj, vrow(j));
+        const T yj = rhoi[j];
+#pragma unroll
+        for (int m = 0; m < MAXM; ++m) acc[m] += vj[m] * yj;
+      }
+#pragma unroll
+      for (int m = 0; m < MAXM; ++m) xv[m] = xv[m] + acc[m];
+    }
+    (void)L;
+  }
+
+  // status + small Krylov arrays of this row's instance -> HBM
+  __device__ __forceinline__ void store_status() const {
+    if (!valid) return;
+    const int kmax = P.kmax, k1 = kmax + 1, ks_all = k1 * k1 + k1 + 3 * kmax;
+    T* dst = P.kry + size_t(b) * ks_all;
+    const T* Hi = S.H + inst * P.Hp;
+    for (int q = r; q < k1 * k1; q += 16) dst[q] = Hi[q];
+    for (int q = r; q < k1; q += 16) dst[k1 * k1 + q] = S.rho[inst * k1 + q];
+    for (int q = r; q < 3 * kmax; q += 16) dst[k1 * k1 + k1 + q] = S.g[inst * 3 * kmax + q];
+    if (r == 0) {
+      P.n_ax[b] = S.nax[inst];
+      P.reason[b] = S.reason[inst];
+    }
+  }
+};
+
+// ---- the tick kernel: cgmres.hpp:78-110 for IPW instances ----------------------------------------
+template <class M, class T, int IPW, int MAXM>
+__global__ __launch_bounds__(IPW * 16) void tick_wg_kernel(WgParams<T> P) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  WgCtx<M, T, IPW, MAXM> C(P, smem);
+  T du[MAXM], bb[MAXM];
+  C.load_common(P.U);
+  C.load_row_to_reg(du, P.dUdt, P.Lg);
+  // H region zeroed so the exported Hessenberg has no stale entries
+  for (int q = C.r; q < P.Hp; q += 16) C.S.H[C.inst * P.Hp + q] = T(0);
+  __syncthreads();
+  C.preamble_sweeps();  // Fh, W = b
+  __syncthreads();
+  C.lds_to_reg(bb, C.S.W);
+  __syncthreads();
+  C.reg_to_lds(C.S.W, du);  // direction of the first mat-vec: x0 = dUdt (warm start, cgmres.hpp:99)
+  __syncthreads();
+  C.ax_sweep(false);  // W <- A dUdt
+  __syncthreads();
+  C.gmres(du, bb);
+  // U += dUdt*dt, u = U[0:dim_u]  (cgmres.hpp:102-109)
+  T un[MAXM];
+  C.lds_to_reg(un, C.S.U);
+#pragma unroll
+  for (int m = 0; m < MAXM; ++m) un[m] = un[m] + du[m] * P.dt;
+  C.reg_to_row(P.U, P.Lg, un);
+  C.reg_to_row(P.dUdt, P.Lg, du);
+  if (C.valid && C.r < M::NU) {
+    P.u_out[size_t(C.b) * M::NU + C.r] = un[0];  // element e = r (m = 0) for r < NU <= 16
+    C.S.U[C.inst * P.Lp + C.r] = un[0];
+  }
+  C.store_status();
+  if (P.x_next) {  // plant step of the example main loop (<example>/main.cpp:71-73)
+    __syncthreads();
+    if (C.sweep_lane) {
+      const int i = C.tid;
+      T x[M::NX], u[M::NU], f[M::NX], tr[M::NC > 0 ? M::NC : 1];
+#pragma unroll
+      for (int c = 0; c < M::NX; ++c) x[c] = C.S.xs[c * IPW + i];
+#pragma unroll
+      for (int j = 0; j < M::NU; ++j) u[j] = C.S.U[i * P.Lp + j];
+      M::dxdt(f, x, u, tr);
+#pragma unroll
+      for (int c = 0; c < M::NX; ++c) P.x_next[size_t(C.bi) * M::NX + c] = x[c] + f[c] * P.dt;
+    }
+  }
+}
+
+// ---- white-box hooks on the same device code -------------------------------------------------------
+template <class M, class T, int IPW, int MAXM>
+__global__ __launch_bounds__(IPW * 16) void hook_wg_kernel(WgParams<T> P) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  WgCtx<M, T, IPW, MAXM> C(P, smem);
+  T a[MAXM], c2[MAXM];
+  const size_t Lrow = P.L;
+  auto load_im = [&](T* reg, const T* src) {  // instance-major [B][L] (no padding) -> registers
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+      const int e = C.elem(m);
+      reg[m] = (C.valid && e < P.L) ? src[size_t(C.b) * Lrow + e] : T(0);
+    }
+  };
+  auto store_im = [&](T* dst, const T* reg) {
+    if (!C.valid) return;
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+      const int e = C.elem(m);
+      if (e < P.L) dst[size_t(C.b) * Lrow + e] = reg[m];
+    }
+  };
+  if (P.mode == WG_HOOK_F) {  // F_func(ret, U, x, t)
+    C.load_common(P.U);
+    __syncthreads();
+    load_im(a, P.hook_in0);
+    C.reg_to_lds(C.S.U, a);
+    __syncthreads();
+    if (C.sweep_lane) {
+      T x[M::NX];
+#pragma unroll
+      for (int c = 0; c < M::NX; ++c) x[c] = C.S.xs[c * IPW + C.tid];
+      f_eval_lds<M, T, IPW, false, F_PLAIN>(P, C.S, C.tid, x, P.hook_dtau, C.S.W + C.tid * P.Lp);
+    }
+    __syncthreads();
+    C.lds_to_reg(a, C.S.W);
+    store_im(P.hook_out, a);
+    return;
+  }
+  if (P.mode == WG_HOOK_PREPARE) {  // cgmres.hpp:83-96
+    C.load_common(P.U);
+    __syncthreads();
+    C.preamble_sweeps();
+    __syncthreads();
+    C.lds_to_reg(a, C.S.W);
+    if (P.hook_out) store_im(P.hook_out, a);
+    C.lds_to_reg(a, C.S.Fh);
+    C.reg_to_row(P.Fh, P.Lg, a);
+    if (C.valid && C.r < M::NX) P.xdxh[size_t(C.b) * M::NX + C.r] = C.S.xh[C.r * IPW + C.inst];
+    return;
+  }
+  // AX / GMRES: state left by PREPARE
+  C.load_common(P.U);
+  C.load_row_to_lds(C.S.Fh, P.Fh);
+  if (C.valid && C.r < M::NX) C.S.xh[C.r * IPW + C.inst] = P.xdxh[size_t(C.b) * M::NX + C.r];
+  for (int q = C.r; q < P.Hp; q += 16) C.S.H[C.inst * P.Hp + q] = T(0);
+  load_im(a, P.hook_in0);
+  C.reg_to_lds(C.S.W, a);
+  __syncthreads();
+  C.ax_sweep(false);
+  __syncthreads();
+  if (P.mode == WG_HOOK_AX) {
+    C.lds_to_reg(a, C.S.W);
+    store_im(P.hook_out, a);
+    return;
+  }
+  load_im(c2, P.hook_in1);
+  C.gmres(a, c2);
+  store_im(P.hook_out, a);
+  C.store_status();
+}
+
+}  // namespace cgm

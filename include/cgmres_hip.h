@@ -68,7 +68,8 @@ typedef struct cgmres_hip_config {
   int32_t dv;          /* Model::dv    horizon stages */
   int32_t k_max;       /* Model::k_max GMRES iterations */
   int32_t device;      /* HIP device ordinal */
-  int32_t variant;     /* kernel mapping: 0 = library default, >0 = explicit */
+  int32_t variant;     /* kernel mapping: 0 = library default, 1 = "lane", 2 = "wg" (DESIGN.md); get_config
+                          returns the resolved value */
   double tol;          /* Model::tol */
   double dt;           /* Model::dt   sampling period */
   double h;            /* Model::h    forward-difference step */
@@ -89,6 +90,8 @@ int cgmres_hip_default_config(int32_t model_id, cgmres_hip_config* cfg);
  * user Model class against the registry: out = [dxdt(dim_x) | dPhidx(dim_x) | dHdx(dim_x) | dHdu(dim_u)]. */
 int cgmres_hip_model_probe(int32_t model_id, int32_t device, const double* x, const double* u, const double* p,
                            const double* lmd, double* out);
+/* Diagnostic: the device sin/cos the horizon sweeps use (fp64), evaluated at n host-supplied arguments. */
+int cgmres_hip_selftest_sincos(int32_t device, const double* a, int32_t n, double* s, double* c);
 const char* cgmres_hip_last_error(void);
 int cgmres_hip_device_count(void);
 

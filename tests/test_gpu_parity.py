@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 U_TOL = 1e-9
 DUDT_REL = 1e-7
-VARIANTS = [0]
+VARIANTS = [2, 1]  # 2 = "wg" (default mapping), 1 = "lane" (reference statement order)
 
 
 def dudt_close(a, b, rel=DUDT_REL):
@@ -260,6 +260,33 @@ def test_status_exit_paths(orc):
     orc.start_controller(r, x0[0], u0[0], p[0])
     assert np.max(np.abs(r.control(x0[0]) - u[0])) <= U_TOL and r.last_solve()[2] == orc.EXIT_SMALL_RESIDUAL
     c.close()
+
+
+def test_device_sincos_accuracy():
+    """The fp64 sin/cos of the horizon sweeps against the host libm: <= 2 ulp of the result on the ranges the
+    models visit (angles around pi, arguments up to the 1e5 cut-over to the library path) and beyond it."""
+    rng = np.random.default_rng(11)
+    a = np.concatenate([rng.uniform(-10, 10, 20000), rng.uniform(-1e5, 1e5, 20000), rng.uniform(-1e9, 1e9, 2000),
+                        np.pi * np.arange(-8, 9) / 2, [0.0, 1e-300, -1e-20, 3.14159265358979, 0.785398163397448]])
+    s, c = cg.selftest_sincos(a)
+    for got, ref in ((s, np.sin(a)), (c, np.cos(a))):
+        err = np.abs(got - ref)
+        # 2 ulp of the result, plus the absolute error of the two-constant argument reduction
+        # (|pi/2 - (PIO2_HI + PIO2_LO)| ~ 6.5e-27 per multiple of pi/2), which only shows next to a zero
+        bound = 2.0 * np.spacing(np.abs(ref)) + 1e-26 * np.maximum(1.0, np.abs(a))
+        assert np.all(err <= bound), float(np.max(err / bound))
+
+
+def test_variant_resolution():
+    a = cg.CgmresBatch("pendulum", batch=4, dv=50, k_max=10)
+    assert a.variant == 2
+    b = cg.CgmresBatch("pendulum", batch=4, dv=50, k_max=10, variant=1)
+    assert b.variant == 1
+    c = cg.CgmresBatch("msd", batch=4, dv=200, k_max=5)  # dim_u*dv = 1200: beyond the wg mapping -> lane
+    assert c.variant == 1
+    with pytest.raises(cg.CgmresHipError):
+        cg.CgmresBatch("msd", batch=4, dv=200, k_max=5, variant=2)
+    a.close(), b.close(), c.close()
 
 
 def test_model_probe_matches_oracle_models(orc):
