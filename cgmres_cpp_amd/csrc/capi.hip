@@ -7,8 +7,8 @@
 //   variant 1 "lane" (tick_lane.hip.h) one lane per instance, reference statement order, any size
 // There is no CPU implementation of the path in this library.
 #include "ctx_common.hip.h"
-#include "ctx_lane.hip.h"
-#include "ctx_wg.hip.h"
+#include "factory.hip.h"
+#include "util_kernels.hip.h"
 
 namespace {
 
@@ -40,26 +40,15 @@ int check_device(int device) {
   return 0;
 }
 
-template <class M, class T>
-cgmres_hip_ctx* make_variant(const cgmres_hip_config& cfg, int* resolved) {
-  int ipw;
-  size_t bytes;
-  const bool wg_ok = cgm::CtxWg<M, T>::supported(cfg, &ipw, &bytes);
-  const int v = cfg.variant == 0 ? (wg_ok ? 2 : 1) : cfg.variant;
-  *resolved = v;
-  if (v == 2) return wg_ok ? new cgm::CtxWg<M, T>() : nullptr;
-  return new cgm::CtxLane<M, T>();
-}
-
-template <class T>
 cgmres_hip_ctx* make_ctx(const cgmres_hip_config& cfg, int* resolved) {
+  const bool f32 = cfg.dtype == CGMRES_HIP_F32;
   switch (cfg.model_id) {
     case CGMRES_HIP_MODEL_PENDULUM:
-      return make_variant<cgm::PendulumDev<T>, T>(cfg, resolved);
+      return f32 ? cgm::make_pendulum_f32(cfg, resolved) : cgm::make_pendulum_f64(cfg, resolved);
     case CGMRES_HIP_MODEL_MSD:
-      return make_variant<cgm::MsdDev<T>, T>(cfg, resolved);
+      return f32 ? cgm::make_msd_f32(cfg, resolved) : cgm::make_msd_f64(cfg, resolved);
     case CGMRES_HIP_MODEL_SEMIACTIVE:
-      return make_variant<cgm::SemiactiveDev<T>, T>(cfg, resolved);
+      return f32 ? cgm::make_semiactive_f32(cfg, resolved) : cgm::make_semiactive_f64(cfg, resolved);
   }
   return nullptr;
 }
@@ -171,7 +160,7 @@ int cgmres_hip_create(const cgmres_hip_config* cfg, cgmres_hip_handle* out) {
   if (cfg->variant < 0 || cfg->variant > 2) return fail(CGMRES_HIP_EINVAL, "unknown variant %d", cfg->variant);
   if (int rc = check_device(cfg->device)) return rc;
   int resolved = 0;
-  cgmres_hip_ctx* c = cfg->dtype == CGMRES_HIP_F32 ? make_ctx<float>(*cfg, &resolved) : make_ctx<double>(*cfg, &resolved);
+  cgmres_hip_ctx* c = make_ctx(*cfg, &resolved);
   if (!c) return fail(CGMRES_HIP_EINVAL, "variant %d does not support model %d with dv = %d, k_max = %d", resolved,
                       cfg->model_id, cfg->dv, cfg->k_max);
   c->cfg = *cfg;

@@ -4,79 +4,139 @@
 //   MsdDev        — mass_spring_damper/model.hpp:36-108        (≡ multiple_controller/model1.hpp)
 //   SemiactiveDev — semiactive_damper/model.hpp:36-69
 // Interface (all static, all inlined into the sweep kernels, scalars in registers):
-//   dxdt  (f, x, u, trig)      state equation; also fills `trig`, the per-stage values the costate
+//   dxdt  (f, x, u, trig, mc)  state equation (mc = per-thread math context: pinned sin/cos constants);
+//                              also fills `trig`, the per-stage values the costate
 //                              sweep needs again (sin/cos of the same arguments — reusing them is
 //                              bit-identical to re-evaluating, and removes 4 of 7 libm-class calls per stage)
 //   dPhidx(g, x, p)            terminal costate
 //   dHdx  (g, x, u, p, l, trig) costate equation
 //   dHdu  (g, x, u, p, l, trig) optimality residual
 //   ddHduu(m, x, u, p, l)      column-major Hessian for init_u0_newton
+//   stage_coeffs / costate_step — the same backward stage regrouped for the "wg" mapping.  For every
+//     Hamiltonian H = L + l^T f the costate right-hand side is affine in l:  dHdx = qx(x,p) + J(x,u)^T l,
+//     and so is dHdu = phi(u) + B(x)^T l.  stage_coeffs(bw, phi, x,u,p,trig,dtau) evaluates everything that does
+//     not involve l (NBW values per stage + the l-free part of dH/du) and can run for all stages at once;
+//     costate_step(l, dF, bw, dtau) is what remains serial: l <- l + dtau*dHdx and dF = B^T l for the first NUL
+//     components of dH/du.  Same mathematics as dHdx/dHdu, different association of the sums.
 // NU_DYN = how many leading components of u the state equation reads (the forward sweep loads only those).
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace cgm {
 
-// sin and cos of one fp64 argument in ~35 VALU instructions (the device libm's sincos costs ~150 with its
-// Payne-Hanek path and dominated the horizon sweep).  Two-constant Cody-Waite reduction by pi/2 — exact for
-// |a| < 1e5 because n*PIO2_HI has <= 50 significant bits — followed by the classic minimax kernels on
-// [-pi/4, pi/4] (coefficients: FreeBSD msun k_sin.c / k_cos.c, public domain; cos assembled in the
-// compensated form w + (((1-w)-hz) + z*r)).  Measured against the host libm in tests: <= 1.5 ulp.
-// Larger arguments take the library path.
-__device__ __forceinline__ void sincos_f64(double a, double* sn, double* cs) {
-  if (__builtin_expect(!(__builtin_fabs(a) < 1.0e5), 0)) {  // also catches NaN
-    ::sincos(a, sn, cs);
-    return;
-  }
-  constexpr double INV_PIO2 = 6.36619772367581382433e-01;
-  constexpr double PIO2_HI = 1.57079632673412561417e+00;  // first 33 bits of pi/2
-  constexpr double PIO2_LO = 6.07710050650619224932e-11;  // pi/2 - PIO2_HI
-  const double n = __builtin_rint(a * INV_PIO2);
-  double r = __builtin_fma(-n, PIO2_HI, a);
-  r = __builtin_fma(-n, PIO2_LO, r);
-  const int q = static_cast<int>(n);
-  const double z = r * r;
-  // sin kernel
-  constexpr double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
-                   S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
-                   S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-  double ps = __builtin_fma(z, S6, S5);
-  ps = __builtin_fma(z, ps, S4);
-  ps = __builtin_fma(z, ps, S3);
-  ps = __builtin_fma(z, ps, S2);
-  ps = __builtin_fma(z, ps, S1);
-  const double ks = __builtin_fma(z * r, ps, r);
-  // cos kernel
-  constexpr double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
-                   C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
-                   C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-  double pc = __builtin_fma(z, C6, C5);
-  pc = __builtin_fma(z, pc, C4);
-  pc = __builtin_fma(z, pc, C3);
-  pc = __builtin_fma(z, pc, C2);
-  pc = __builtin_fma(z, pc, C1);
-  const double hz = 0.5 * z;
-  const double w = 1.0 - hz;
-  const double kc = w + (((1.0 - w) - hz) + z * (z * pc));
-  // quadrant: sin = {s, c, -s, -c}[q&3], cos = {c, -s, -c, s}[q&3]
-  const bool odd = q & 1;
-  const double ss = odd ? kc : ks;
-  const double cc = odd ? ks : kc;
-  const int sflip = (q & 2) << 30, cflip = ((q + 1) & 2) << 30;
-  *sn = __hiloint2double(__double2hiint(ss) ^ sflip, __double2loint(ss));
-  *cs = __hiloint2double(__double2hiint(cc) ^ cflip, __double2loint(cc));
+// fp64 sin/cos for the horizon sweeps.  The device libm's sincos costs ~150 VALU instructions per call with
+// its Payne-Hanek path and dominated the sweep; this one is ~35 per argument:
+//   * two-constant Cody-Waite reduction by pi/2, exact for |a| < 1e5 (n*PIO2_HI has <= 50 significant bits);
+//   * the classic minimax kernels on [-pi/4, pi/4] (coefficients: FreeBSD msun k_sin.c / k_cos.c, public
+//     domain), cos assembled in the compensated form w + (((1-w)-hz) + z*r);
+//   * Horner steps issued as 3-operand v_fma_f64 (hipcc otherwise turns fma(z,p,CONST) into v_mov + v_fmac),
+//     and the chains of the two arguments / two kernels interleaved so four independent FMA chains are in
+//     flight (one wave per SIMD cannot hide the dependent-issue latency otherwise).
+// Accuracy (tests/test_gpu_parity.py::test_device_sincos_accuracy): <= 2 ulp + 1e-26*|a|.
+// Arguments outside the fast range (or NaN) take the library path through one wave-uniform branch.
+__device__ __forceinline__ double fma3(double a, double b, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
 }
 
+// The 15 fp64 constants of the routine, held in VGPRs for the lifetime of a thread.  They are made opaque
+// to the optimiser on purpose: with the scalar register file saturated by the kernel's pointers hipcc would
+// otherwise re-materialise every constant in every stage (22 s_mov + 12 v_mov per sincos pair).
+struct TrigConsts {
+  double inv_pio2, pio2_hi, pio2_lo, S1, S2, S3, S4, S5, S6, C1, C2, C3, C4, C5, C6;
+  __device__ __forceinline__ void init() {
+    inv_pio2 = 6.36619772367581382433e-01;
+    pio2_hi = 1.57079632673412561417e+00;  // first 33 bits of pi/2
+    pio2_lo = 6.07710050650619224932e-11;  // pi/2 - pio2_hi
+    S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04;
+    S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05;
+    C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    asm volatile("" : "+v"(inv_pio2), "+v"(pio2_hi), "+v"(pio2_lo));
+    asm volatile("" : "+v"(S1), "+v"(S2), "+v"(S3), "+v"(S4), "+v"(S5), "+v"(S6));
+    asm volatile("" : "+v"(C1), "+v"(C2), "+v"(C3), "+v"(C4), "+v"(C5), "+v"(C6));
+  }
+};
+struct NoConsts {
+  __device__ __forceinline__ void init() {}
+};
+
+struct SinCosKernel {
+  double r, z, ps, pc;
+  int q;
+  __device__ __forceinline__ void reduce(double a, const TrigConsts& K) {
+    const double n = __builtin_rint(a * K.inv_pio2);
+    r = __builtin_fma(-n, K.pio2_hi, a);
+    r = __builtin_fma(-n, K.pio2_lo, r);
+    q = static_cast<int>(n);
+    z = r * r;
+  }
+  __device__ __forceinline__ void finish(double* sn, double* cs) const {
+    const double ks = fma3(z * r, ps, r);
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    const double kc = w + (((1.0 - w) - hz) + z * (z * pc));
+    // quadrant: sin = {s, c, -s, -c}[q&3], cos = {c, -s, -c, s}[q&3]
+    const bool odd = q & 1;
+    const double ss = odd ? kc : ks;
+    const double cc = odd ? ks : kc;
+    const int sflip = (q & 2) << 30, cflip = ((q + 1) & 2) << 30;
+    *sn = __hiloint2double(__double2hiint(ss) ^ sflip, __double2loint(ss));
+    *cs = __hiloint2double(__double2hiint(cc) ^ cflip, __double2loint(cc));
+  }
+};
+
+// sin/cos of two arguments at once (the pendulum needs sin/cos of x0-x1 and of x1 in every stage)
+__device__ __forceinline__ void sincos2_f64(double a0, double a1, double* s0, double* c0, double* s1, double* c1,
+                                            const TrigConsts& K) {
+  const bool bad = !(__builtin_fabs(a0) < 1.0e5) || !(__builtin_fabs(a1) < 1.0e5);  // also catches NaN
+  if (__builtin_expect(__any(bad), 0)) {
+    ::sincos(a0, s0, c0);
+    ::sincos(a1, s1, c1);
+    return;
+  }
+  SinCosKernel k0, k1;
+  k0.reduce(a0, K);
+  k1.reduce(a1, K);
+  k0.ps = fma3(k0.z, K.S6, K.S5), k1.ps = fma3(k1.z, K.S6, K.S5);
+  k0.pc = fma3(k0.z, K.C6, K.C5), k1.pc = fma3(k1.z, K.C6, K.C5);
+  k0.ps = fma3(k0.z, k0.ps, K.S4), k1.ps = fma3(k1.z, k1.ps, K.S4);
+  k0.pc = fma3(k0.z, k0.pc, K.C4), k1.pc = fma3(k1.z, k1.pc, K.C4);
+  k0.ps = fma3(k0.z, k0.ps, K.S3), k1.ps = fma3(k1.z, k1.ps, K.S3);
+  k0.pc = fma3(k0.z, k0.pc, K.C3), k1.pc = fma3(k1.z, k1.pc, K.C3);
+  k0.ps = fma3(k0.z, k0.ps, K.S2), k1.ps = fma3(k1.z, k1.ps, K.S2);
+  k0.pc = fma3(k0.z, k0.pc, K.C2), k1.pc = fma3(k1.z, k1.pc, K.C2);
+  k0.ps = fma3(k0.z, k0.ps, K.S1), k1.ps = fma3(k1.z, k1.ps, K.S1);
+  k0.pc = fma3(k0.z, k0.pc, K.C1), k1.pc = fma3(k1.z, k1.pc, K.C1);
+  k0.finish(s0, c0);
+  k1.finish(s1, c1);
+}
+
+__device__ __forceinline__ void sincos_f64(double a, double* sn, double* cs) {
+  TrigConsts K;
+  K.init();
+  double s1, c1;
+  sincos2_f64(a, a, sn, cs, &s1, &c1, K);
+}
+
+// Per-scalar-type math context handed to the model functions.
 template <class T>
-__device__ __forceinline__ void sincos_t(T a, T* s, T* c);
+struct MathCtx;
 template <>
-__device__ __forceinline__ void sincos_t<double>(double a, double* s, double* c) {
-  sincos_f64(a, s, c);
-}
+struct MathCtx<double> : TrigConsts {
+  __device__ __forceinline__ void sincos_pair(double a0, double a1, double* s0, double* c0, double* s1,
+                                              double* c1) const {
+    sincos2_f64(a0, a1, s0, c0, s1, c1, *this);
+  }
+};
 template <>
-__device__ __forceinline__ void sincos_t<float>(float a, float* s, float* c) {
-  ::sincosf(a, s, c);
-}
+struct MathCtx<float> : NoConsts {
+  __device__ __forceinline__ void sincos_pair(float a0, float a1, float* s0, float* c0, float* s1, float* c1) const {
+    ::sincosf(a0, s0, c0);
+    ::sincosf(a1, s1, c1);
+  }
+};
 
 struct ModelInfo {
   int dim_x, dim_u, dim_p, dv, k_max;
@@ -97,10 +157,10 @@ struct PendulumDev {
   static constexpr T A32a = T(5.65635), A32 = T(0.905016), A32b = T(14.1183);
 
   // trig = { sin(x0-x1), cos(x0-x1), cos(x1) }
-  static __device__ __forceinline__ void dxdt(T* f, const T* x, const T* u, T* trig) {  // model.hpp:37-42
+  using Math = MathCtx<T>;
+  static __device__ __forceinline__ void dxdt(T* f, const T* x, const T* u, T* trig, const Math& mc) {  // model.hpp:37-42
     T sd, cd, s1, c1;
-    sincos_t<T>(x[0] - x[1], &sd, &cd);
-    sincos_t<T>(x[1], &s1, &c1);
+    mc.sincos_pair(x[0] - x[1], x[1], &sd, &cd, &s1, &c1);
     trig[0] = sd;
     trig[1] = cd;
     trig[2] = c1;
@@ -130,6 +190,36 @@ struct PendulumDev {
     g[1] = T(-0.5) * r1 + (T(2.0) * u[2] * u[1]);
     g[2] = (u[0] - uc) * (u[0] - uc) + u[1] * u[1] - ur * ur;
   }
+  // --- affine-in-costate split of the backward stage (see the interface note at the top of the file) ---
+  // dHdx = qx(x,p) + J(x,u)^T l and dHdu = phi(u) + B(x)^T l (model.hpp:51-62 regrouped); q2 = q3 = 0 here,
+  // so the l-free parts of rows 2,3 vanish and are not stored.
+  static constexpr int NBW = 6, NUL = 1;
+  static_assert(q2 == T(0.0) && q3 == T(0.0), "pendulum stage coefficients assume q2 = q3 = 0");
+  static __device__ __forceinline__ void stage_coeffs(T* bw, T* phi, const T* x, const T* u, const T* p,
+                                                      const T* trig, T dtau) {
+    const T sd = trig[0], cd = trig[1], c1 = trig[2];
+    const T S0 = A32 * x[2] * x[2] * cd + A32b * sd * u[0] - A32a * sd * x[2];                  // l3 coeff, row 0
+    const T S1 = -A32 * x[2] * x[2] * cd + A52 * c1 - A32b * sd * u[0] + A32a * sd * x[2];      // l3 coeff, row 1
+    const T S2 = T(2.0) * A32 * x[2] * sd + A32a * cd + C22;                                    // l3 coeff, row 2
+    bw[0] = dtau * ((x[0] - p[0]) * q0);
+    bw[1] = dtau * S0;
+    bw[2] = dtau * ((x[1] - p[1]) * q1);
+    bw[3] = dtau * S1;
+    bw[4] = dtau * S2;
+    bw[5] = -A32b * cd;  // l3 coeff of dHdu[0]
+    phi[0] = (r0 * u[0]) + (u[2] * (T(2.0) * u[0] - T(2.0) * uc));
+    phi[1] = T(-0.5) * r1 + (T(2.0) * u[2] * u[1]);
+    phi[2] = (u[0] - uc) * (u[0] - uc) + u[1] * u[1] - ur * ur;
+  }
+  // l <- l + dtau*dHdx(l) and dF = B^T l_old, from the stored coefficients
+  static __device__ __forceinline__ void costate_step(T* l, T* dF, const T* bw, T dtau) {
+    dF[0] = l[2] * Bs + bw[5] * l[3];
+    const T n0 = (l[0] + bw[0]) + bw[1] * l[3];
+    const T n1 = (l[1] + bw[2]) + bw[3] * l[3];
+    const T n2 = l[2] + (dtau * (l[0] - l[2] * As) + bw[4] * l[3]);
+    const T n3 = l[3] + dtau * (l[1] - l[3] * C22);
+    l[0] = n0, l[1] = n1, l[2] = n2, l[3] = n3;
+  }
   static __device__ __forceinline__ void ddHduu(T* m, const T*, const T* u, const T*, const T*) {  // :64-76
     m[0] = r0 + 2 * u[2];
     m[1] = 0;
@@ -154,7 +244,8 @@ struct MsdDev {
   static constexpr T uc = T(0.0), ur = T(10.0);  // umin=-10, umax=10 (model.hpp:117-120)
   static constexpr T m1 = T(1.0), m2 = T(1.0), d1 = T(1.0), d2 = T(1.0), k1 = T(1.0), k2 = T(1.0);
 
-  static __device__ __forceinline__ void dxdt(T* f, const T* x, const T* u, T*) {  // model.hpp:36-41
+  using Math = NoConsts;
+  static __device__ __forceinline__ void dxdt(T* f, const T* x, const T* u, T*, const Math&) {  // model.hpp:36-41
     f[0] = x[2];
     f[1] = x[3];
     // dxdt uses (k1*k2), dHdx below uses (k1+k2): the reference's own inconsistency, kept
@@ -182,6 +273,30 @@ struct MsdDev {
     g[3] = -r3 + T(2.0) * u[5] * u[3];
     g[4] = (u[0] - uc) * (u[0] - uc) + u[2] * u[2] - ur * ur;
     g[5] = (u[1] - uc) * (u[1] - uc) + u[3] * u[3] - ur * ur;
+  }
+  // affine-in-costate split (model.hpp:50-64 regrouped): the Jacobian is constant, only qx depends on the stage
+  static constexpr int NBW = 4, NUL = 2;
+  static __device__ __forceinline__ void stage_coeffs(T* bw, T* phi, const T* x, const T* u, const T* p, const T*,
+                                                      T dtau) {
+    bw[0] = dtau * (-(p[0] - x[0]) * q0);
+    bw[1] = dtau * (-(p[1] - x[1]) * q1);
+    bw[2] = dtau * (x[2] * q2);
+    bw[3] = dtau * (x[3] * q3);
+    phi[0] = r0 * u[0] + T(2.0) * u[4] * (u[0] - uc);
+    phi[1] = r1 * u[1] + T(2.0) * u[5] * (u[1] - uc);
+    phi[2] = -r2 + T(2.0) * u[4] * u[2];
+    phi[3] = -r3 + T(2.0) * u[5] * u[3];
+    phi[4] = (u[0] - uc) * (u[0] - uc) + u[2] * u[2] - ur * ur;
+    phi[5] = (u[1] - uc) * (u[1] - uc) + u[3] * u[3] - ur * ur;
+  }
+  static __device__ __forceinline__ void costate_step(T* l, T* dF, const T* bw, T dtau) {
+    dF[0] = l[2] / m1;
+    dF[1] = l[3] / m2;
+    const T n0 = (l[0] + bw[0]) + dtau * (-(k1 + k2) / m1 * l[2] + k2 / m2 * l[3]);
+    const T n1 = (l[1] + bw[1]) + dtau * (k2 / m1 * l[2] - k2 / m2 * l[3]);
+    const T n2 = (l[2] + bw[2]) + dtau * (l[0] - (d1 + d2) / m1 * l[2] + d2 / m2 * l[3]);
+    const T n3 = (l[3] + bw[3]) + dtau * (l[1] + d2 / m1 * l[2] - d2 / m2 * l[3]);
+    l[0] = n0, l[1] = n1, l[2] = n2, l[3] = n3;
   }
   static __device__ __forceinline__ void ddHduu(T* m, const T*, const T* u, const T*, const T*) {  // :66-108
 #pragma unroll
@@ -211,7 +326,8 @@ struct SemiactiveDev {
   static constexpr T uc = T(0.5), ur = T(0.5);  // umin=0, umax=1 (model.hpp:79-82)
   static constexpr T a = T(-1.0), b = T(-1.0);  // model.hpp:85-86
 
-  static __device__ __forceinline__ void dxdt(T* f, const T* x, const T* u, T*) {  // model.hpp:36-39
+  using Math = NoConsts;
+  static __device__ __forceinline__ void dxdt(T* f, const T* x, const T* u, T*, const Math&) {  // model.hpp:36-39
     f[0] = x[1];
     f[1] = a * x[0] + b * u[0] * x[1];
   }
@@ -229,6 +345,24 @@ struct SemiactiveDev {
     g[0] = r0 * u[0] + b * x[1] * l[1] + 2 * u[2] * (u[0] - uc);
     g[1] = -r1 + 2 * u[1] * u[2];
     g[2] = (u[0] - uc) * (u[0] - uc) + u[1] * u[1] - ur * ur;
+  }
+  // affine-in-costate split (model.hpp:46-55 regrouped)
+  static constexpr int NBW = 4, NUL = 1;
+  static __device__ __forceinline__ void stage_coeffs(T* bw, T* phi, const T* x, const T* u, const T*, const T*,
+                                                      T dtau) {
+    bw[0] = dtau * (x[0] * q0);
+    bw[1] = dtau * (x[1] * q1);
+    bw[2] = dtau * (b * u[0]);  // l1 coeff, row 1
+    bw[3] = b * x[1];           // l1 coeff of dHdu[0]
+    phi[0] = r0 * u[0] + 2 * u[2] * (u[0] - uc);
+    phi[1] = -r1 + 2 * u[1] * u[2];
+    phi[2] = (u[0] - uc) * (u[0] - uc) + u[1] * u[1] - ur * ur;
+  }
+  static __device__ __forceinline__ void costate_step(T* l, T* dF, const T* bw, T dtau) {
+    dF[0] = bw[3] * l[1];
+    const T n0 = (l[0] + bw[0]) + dtau * (a * l[1]);
+    const T n1 = (l[1] + bw[1]) + (dtau * l[0] + bw[2] * l[1]);
+    l[0] = n0, l[1] = n1;
   }
   static __device__ __forceinline__ void ddHduu(T* m, const T*, const T* u, const T*, const T*) {  // :57-69
     m[0] = r0 + 2 * u[2];

@@ -46,6 +46,8 @@ __device__ __forceinline__ void f_eval_lane(const TickParams<T>& P, size_t ld, c
                                             T* __restrict__ traj, T* __restrict__ trig,
                                             const T* __restrict__ ptau) {
   constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC;
+  typename M::Math mc;
+  mc.init();
   T xs[NX];
 #pragma unroll
   for (int i = 0; i < NX; ++i) xs[i] = x0[i];
@@ -61,7 +63,7 @@ __device__ __forceinline__ void f_eval_lane(const TickParams<T>& P, size_t ld, c
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) traj[size_t(s * NX + i) * ld] = xs[i];
-    M::dxdt(f, xs, u, tr);
+    M::dxdt(f, xs, u, tr, mc);
 #pragma unroll
     for (int c = 0; c < NC; ++c) trig[size_t(s * NC + c) * ld] = tr[c];
 #pragma unroll
@@ -116,9 +118,11 @@ template <class M, class T>
 __device__ __forceinline__ void prepare_lane(const TickParams<T>& P, size_t ld, const LaneView<T>& A, const T* x) {
   constexpr int NX = M::NX, NU = M::NU;
   T u0[NU], f[NX], xh[NX], tr[M::NC > 0 ? M::NC : 1];
+  typename M::Math mc;
+  mc.init();
 #pragma unroll
   for (int j = 0; j < NU; ++j) u0[j] = A.U[size_t(j) * ld];
-  M::dxdt(f, x, u0, tr);  // cgmres.hpp:83
+  M::dxdt(f, x, u0, tr, mc);  // cgmres.hpp:83
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
     xh[i] = f[i] * P.h + x[i];  // :84-85
@@ -265,7 +269,9 @@ __global__ __launch_bounds__(64) void tick_lane_kernel(TickParams<T> P) {
   }
   if (P.x_next) {  // */main.cpp:71-73 plant step (Simulator::dxdt has the Model's state equation)
     T f[M::NX], tr[M::NC > 0 ? M::NC : 1];
-    M::dxdt(f, x, u, tr);
+    typename M::Math mc;
+    mc.init();
+    M::dxdt(f, x, u, tr, mc);
 #pragma unroll
     for (int i = 0; i < M::NX; ++i) P.x_next[size_t(b) * M::NX + i] = x[i] + f[i] * P.dt;
   }

@@ -6,17 +6,21 @@
 //     Dot products / norms are lane partial sums + a 4-step DPP butterfly inside the row
 //     (quad_perm, quad_perm, row_half_mirror, row_mirror): every lane of the row ends with the
 //     bit-identical sum, so row-uniform branches (early exit, breakdown) never diverge inside a row.
-//   * the horizon sweeps (F_func) are serial in the stage index, so they run one lane per instance
-//     on lanes 0..IPW-1 of wave 0, with U, F(U,x+hf,t+h), the work vector, the state trajectory, the
-//     reusable trig values and ptau all staged in LDS (odd row pitches: conflict-free for the
-//     16 sweep lanes).  No HBM access inside the stage loops.
+//   * a horizon sweep (F_func, cgmres.hpp:113-162) has three phases:
+//       1. state sweep  — serial in the stage index: one lane per instance (lanes 0..IPW-1 of wave 0),
+//                         x(s) and the reusable trig values go to the LDS stage table R;
+//       2. coefficients — everything of the backward stage that does not involve the costate (dHdx and dHdu
+//                         are affine in it, models.hip.h) for ALL (stage, instance) pairs at once, by all threads;
+//       3. costate sweep — serial again, but only the short affine recurrence is left (pendulum: 14 fp64 ops
+//                         per stage instead of 46), fused with the costate part of dH/du.
+//     U, F(U,x+hf,t+h), the work vector, the stage table and ptau all sit in LDS (odd row pitches: conflict-free
+//     for the sweep lanes); there is no HBM access inside the stage loops.
 //   * the Krylov basis V (IPW x (k_max+1) x L) does not fit in 160 KB of LDS at IPW = 16, it lives in
 //     HBM/L2 as instance-major rows (each row-load is one 128-byte segment per 16 lanes) and is
 //     streamed once per Gram-Schmidt step — exactly the traffic SURVEY.md §8(d) prices.
-//   * instances never exchange data: the only synchronisation is the workgroup barrier between
-//     the sweep phase and the vector phase.
-// Statement order inside each instance follows cgmres.hpp:78-175 / gmres.hpp:28-112; what differs
-// from the reference is the association order of the length-L sums (16 partial sums + butterfly).
+//   * instances never exchange data: the only synchronisation is the workgroup barrier between phases.
+// Statement order inside each instance follows cgmres.hpp:78-175 / gmres.hpp:28-112; what differs from the
+// reference is the association order of sums (16 partial sums + butterfly; affine regrouping of the costate step).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -75,12 +79,15 @@ __device__ __forceinline__ T row16_sum(T x) {
 // ---- LDS carve-up -------------------------------------------------------------------------------
 template <class M, class T, int IPW>
 struct WgLds {
-  T *U, *Fh, *W, *traj, *trig, *p, *H, *rho, *g, *xs, *xh;
+  // stage table: NSTG values per (stage, instance), layout [stage][slot][IPW]
+  //   after phase 1: slots 0..NX-1 = x(s), NX..NX+NC-1 = trig(s);  after phase 2: slots 0..NBW-1 = costate coefficients
+  static constexpr int NSTG = (M::NX + M::NC) > M::NBW ? (M::NX + M::NC) : M::NBW;
+  T *U, *Fh, *W, *R, *p, *H, *rho, *g, *xs, *xh;
   int *flag, *reason, *nax, *ksolve;
   static __host__ __device__ size_t count_T(int dv, int kmax, int Lp, int Pp, int Hp) {
     const int k1 = kmax + 1;
-    return size_t(3) * IPW * Lp + size_t(dv) * (M::NX + M::NC) * IPW + size_t(IPW) * Pp + size_t(IPW) * Hp +
-           size_t(IPW) * k1 + size_t(IPW) * 3 * kmax + size_t(2) * M::NX * IPW;
+    return size_t(3) * IPW * Lp + size_t(dv) * NSTG * IPW + size_t(IPW) * Pp + size_t(IPW) * Hp + size_t(IPW) * k1 +
+           size_t(IPW) * 3 * kmax + size_t(2) * M::NX * IPW;
   }
   static __host__ __device__ size_t bytes(int dv, int kmax, int Lp, int Pp, int Hp) {
     return count_T(dv, kmax, Lp, Pp, Hp) * sizeof(T) + 4 * IPW * sizeof(int) + 16;
@@ -91,8 +98,7 @@ struct WgLds {
     U = q, q += IPW * P.Lp;
     Fh = q, q += IPW * P.Lp;
     W = q, q += IPW * P.Lp;
-    traj = q, q += P.dv * M::NX * IPW;
-    trig = q, q += P.dv * M::NC * IPW;
+    R = q, q += P.dv * NSTG * IPW;
     p = q, q += IPW * P.Pp;
     H = q, q += IPW * P.Hp;
     rho = q, q += IPW * k1;
@@ -104,87 +110,25 @@ struct WgLds {
   }
 };
 
-// ---- horizon sweep on LDS, one lane per instance (cgmres.hpp:113-162, :168-174) -------------------
-//   MODE F_PLAIN: out = F            F_RHS: out = (F*(1-zeta h) - Fh)/h          F_AX: out = (F - Fh)/h
-//   PERT: u = U + h*W (W is both the direction v and, afterwards, the output when `out` aliases it:
-//   stage s of `out` is written after the last read of W[s], so in-place is safe).
-template <class M, class T, int IPW, bool PERT, int MODE>
-__device__ __forceinline__ void f_eval_lds(const WgParams<T>& P, const WgLds<M, T, IPW>& S, int i, const T* x0,
-                                           T dtau, T* out) {
-  constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC;
-  const T* __restrict__ U = S.U + i * P.Lp;
-  const T* W = S.W + i * P.Lp;  // may alias `out` (in-place Ax)
-  const T* __restrict__ Fh = S.Fh + i * P.Lp;
-  const T* __restrict__ pt = S.p + i * P.Pp;
-  T* __restrict__ traj = S.traj + i;
-  T* __restrict__ trig = S.trig + i;
-  const int dv = P.dv;
-  T xs[NX];
-#pragma unroll
-  for (int c = 0; c < NX; ++c) xs[c] = x0[c];
-  for (int s = 0; s < dv; ++s) {  // cgmres.hpp:133-140
-    T u[M::NU_DYN], f[NX], tr[NC > 0 ? NC : 1];
-#pragma unroll
-    for (int j = 0; j < M::NU_DYN; ++j) {
-      T uj = U[s * NU + j];
-      if (PERT) uj = W[s * NU + j] * P.h + uj;
-      u[j] = uj;
-    }
-#pragma unroll
-    for (int c = 0; c < NX; ++c) traj[(s * NX + c) * IPW] = xs[c];
-    M::dxdt(f, xs, u, tr);
-#pragma unroll
-    for (int c = 0; c < NC; ++c) trig[(s * NC + c) * IPW] = tr[c];
-#pragma unroll
-    for (int c = 0; c < NX; ++c) xs[c] = f[c] * dtau + xs[c];
-  }
-  T l[NX], p[NP > 0 ? NP : 1];
-#pragma unroll
-  for (int j = 0; j < NP; ++j) p[j] = pt[dv * NP + j];
-  M::dPhidx(l, xs, p);  // cgmres.hpp:145
-  for (int s = dv - 1; s >= 0; --s) {  // cgmres.hpp:146-161
-    T u[NU], tr[NC > 0 ? NC : 1], Fs[NU], gx[NX];
-#pragma unroll
-    for (int c = 0; c < NX; ++c) xs[c] = traj[(s * NX + c) * IPW];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) tr[c] = trig[(s * NC + c) * IPW];
-#pragma unroll
-    for (int j = 0; j < NU; ++j) {
-      T uj = U[s * NU + j];
-      if (PERT) uj = W[s * NU + j] * P.h + uj;
-      u[j] = uj;
-    }
-#pragma unroll
-    for (int j = 0; j < NP; ++j) p[j] = pt[s * NP + j];
-    M::dHdu(Fs, xs, u, p, l, tr);
-#pragma unroll
-    for (int j = 0; j < NU; ++j) {
-      T rj = Fs[j];
-      if (MODE == F_RHS) rj = (rj * P.one_m_zh - Fh[s * NU + j]) * P.inv_h;
-      if (MODE == F_AX) rj = (rj - Fh[s * NU + j]) * P.inv_h;
-      out[s * NU + j] = rj;
-    }
-    M::dHdx(gx, xs, u, p, l, tr);
-#pragma unroll
-    for (int c = 0; c < NX; ++c) l[c] = gx[c] * dtau + l[c];
-  }
-}
-
 // Per-thread view of one workgroup's job.
 template <class M, class T, int IPW, int MAXM>
 struct WgCtx {
+  using Lds = WgLds<M, T, IPW>;
+  static constexpr int NSTG = Lds::NSTG;
   const WgParams<T>& P;
-  WgLds<M, T, IPW> S;
+  Lds S;
   int tid, inst, r, b;  // b = global instance of this thread's row
   bool valid;           // row has a real instance
-  bool sweep_lane;      // this thread runs horizon sweeps (for instance `tid`)
+  bool sweep_lane;      // this thread runs the serial sweeps (for instance `tid`)
   int bi;               // global instance of the sweep lane
+  typename M::Math mc;  // per-thread math context (pinned sin/cos constants)
   __device__ WgCtx(const WgParams<T>& P_, unsigned char* smem)
       : P(P_), S(smem, P_), tid(threadIdx.x), inst(threadIdx.x >> 4), r(threadIdx.x & 15) {
     b = blockIdx.x * IPW + inst;
     valid = b < P.B;
     bi = blockIdx.x * IPW + tid;
     sweep_lane = tid < IPW && bi < P.B;
+    mc.init();
   }
   __device__ __forceinline__ int elem(int m) const { return r + 16 * m; }
 
@@ -260,40 +204,148 @@ struct WgCtx {
     }
   }
 
-  // cgmres.hpp:83-96 on the sweep lanes: x_dxh, Fh = F(U, x_dxh, t+h), W = b.
-  __device__ __forceinline__ void preamble_sweeps() {
+  // ---- horizon sweep (cgmres.hpp:113-162; with PERT also :168-169, with MODE the post-processing) ------------
+  //   MODE F_PLAIN: out = F        F_RHS: out = (F*(1-zeta h) - Fh)/h  (:91-96)        F_AX: out = (F - Fh)/h  (:173-174)
+  //   PERT: u = U + h*W.  `out` may be W itself: every (stage, instance) entry of W is read for the last time in
+  //   phase 2 by the thread that then overwrites it.
+  // COLLECTIVE: every thread of the block must call it (two workgroup barriers inside); the caller adds the
+  // barrier that publishes `out`.  x0c = initial state, component-major LDS [c*IPW + i].
+  template <bool PERT, int MODE>
+  __device__ __forceinline__ void f_eval(const T* x0c, T dtau, T* out, bool only_active) {
+    constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC, NBW = M::NBW, NUL = M::NUL;
+    const int dv = P.dv;
+    const bool go = sweep_lane && (!only_active || S.flag[tid]);
+    T xs[NX];
+    // phase 1: state sweep, cgmres.hpp:132-140
+    if (go) {
+      const int i = tid;
+      const T* __restrict__ U = S.U + i * P.Lp;
+      const T* W = S.W + i * P.Lp;
+      T* __restrict__ R = S.R + i;
+#pragma unroll
+      for (int c = 0; c < NX; ++c) xs[c] = x0c[c * IPW + i];
+      for (int s = 0; s < dv; ++s) {
+        T u[M::NU_DYN], f[NX], tr[NC > 0 ? NC : 1];
+#pragma unroll
+        for (int j = 0; j < M::NU_DYN; ++j) {
+          T uj = U[s * NU + j];
+          if (PERT) uj = W[s * NU + j] * P.h + uj;
+          u[j] = uj;
+        }
+#pragma unroll
+        for (int c = 0; c < NX; ++c) R[(s * NSTG + c) * IPW] = xs[c];
+        M::dxdt(f, xs, u, tr, mc);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) R[(s * NSTG + NX + c) * IPW] = tr[c];
+#pragma unroll
+        for (int c = 0; c < NX; ++c) xs[c] = f[c] * dtau + xs[c];
+      }
+    }
+    __syncthreads();
+    // phase 2: costate-free part of every backward stage, all threads, items (s, i) with i fastest
+    {
+      const T sc_phi = MODE == F_RHS ? P.one_m_zh : T(1.0);
+      for (int q = tid; q < dv * IPW; q += IPW * 16) {
+        const int i = q & (IPW - 1), s = q / IPW;
+        if (blockIdx.x * IPW + i >= P.B) continue;
+        if (only_active && !S.flag[i]) continue;
+        T x[NX], tr[NC > 0 ? NC : 1], u[NU], p[NP > 0 ? NP : 1], bw[NBW], phi[NU];
+        T* R = S.R + (s * NSTG) * IPW + i;
+#pragma unroll
+        for (int c = 0; c < NX; ++c) x[c] = R[c * IPW];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) tr[c] = R[(NX + c) * IPW];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+          T uj = S.U[i * P.Lp + s * NU + j];
+          if (PERT) uj = S.W[i * P.Lp + s * NU + j] * P.h + uj;
+          u[j] = uj;
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) p[j] = S.p[i * P.Pp + s * NP + j];
+        M::stage_coeffs(bw, phi, x, u, p, tr, dtau);
+#pragma unroll
+        for (int c = 0; c < NBW; ++c) R[c * IPW] = bw[c];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+          T rj = phi[j];
+          if (MODE != F_PLAIN) rj = (rj * sc_phi - S.Fh[i * P.Lp + s * NU + j]) * P.inv_h;
+          out[i * P.Lp + s * NU + j] = rj;
+        }
+      }
+    }
+    __syncthreads();
+    // phase 3: costate sweep (cgmres.hpp:145-153) + the costate part of dH/du (:156-161)
+    if (go) {
+      const int i = tid;
+      const T sc = MODE == F_PLAIN ? T(1.0) : (MODE == F_RHS ? P.one_m_zh * P.inv_h : P.inv_h);
+      T l[NX], p[NP > 0 ? NP : 1];
+#pragma unroll
+      for (int j = 0; j < NP; ++j) p[j] = S.p[i * P.Pp + dv * NP + j];
+      M::dPhidx(l, xs, p);
+      T* o = out + i * P.Lp;
+      const T* R = S.R + i;
+      // two register sets, unrolled by two: the LDS operands of stage s-1 are in flight while stage s computes
+      struct Ops {
+        T bw[NBW], o[NUL];
+      };
+      auto fetch = [&](Ops& a, int s) {
+#pragma unroll
+        for (int c = 0; c < NBW; ++c) a.bw[c] = R[(s * NSTG + c) * IPW];
+#pragma unroll
+        for (int j = 0; j < NUL; ++j) a.o[j] = o[s * NU + j];
+      };
+      auto stage = [&](const Ops& a, int s) {
+        T dF[NUL];
+        M::costate_step(l, dF, a.bw, dtau);
+#pragma unroll
+        for (int j = 0; j < NUL; ++j) o[s * NU + j] = a.o[j] + dF[j] * sc;
+      };
+      Ops A, B;
+      int s = dv - 1;
+      fetch(A, s);
+      for (; s >= 1; s -= 2) {
+        fetch(B, s - 1);
+        stage(A, s);
+        if (s >= 2) fetch(A, s - 2);
+        stage(B, s - 1);
+      }
+      if (s == 0) stage(A, 0);
+    }
+  }
+
+  // cgmres.hpp:83-85 on the sweep lanes: x_dxh = x + h*f(x, U0)
+  __device__ __forceinline__ void make_xh() {
     if (!sweep_lane) return;
     constexpr int NX = M::NX;
     const int i = tid;
-    T x[NX], u0[M::NU], f[NX], xh[NX], tr[M::NC > 0 ? M::NC : 1];
+    T x[NX], u0[M::NU], f[NX], tr[M::NC > 0 ? M::NC : 1];
 #pragma unroll
     for (int c = 0; c < NX; ++c) x[c] = S.xs[c * IPW + i];
 #pragma unroll
     for (int j = 0; j < M::NU; ++j) u0[j] = S.U[i * P.Lp + j];
-    M::dxdt(f, x, u0, tr);
+    M::dxdt(f, x, u0, tr, mc);
 #pragma unroll
-    for (int c = 0; c < NX; ++c) {
-      xh[c] = f[c] * P.h + x[c];
-      S.xh[c * IPW + i] = xh[c];
-    }
-    f_eval_lds<M, T, IPW, false, F_PLAIN>(P, S, i, xh, P.dtau_h, S.Fh + i * P.Lp);
-    f_eval_lds<M, T, IPW, false, F_RHS>(P, S, i, x, P.dtau_0, S.W + i * P.Lp);
+    for (int c = 0; c < NX; ++c) S.xh[c * IPW + i] = f[c] * P.h + x[c];
   }
-  // Ax_func in place on W for the sweep lanes whose instance is active (cgmres.hpp:164-175)
-  __device__ __forceinline__ void ax_sweep(bool only_active) {
-    if (!sweep_lane) return;
-    const int i = tid;
-    if (only_active && !S.flag[i]) return;
-    T xh[M::NX];
-#pragma unroll
-    for (int c = 0; c < M::NX; ++c) xh[c] = S.xh[c * IPW + i];
-    f_eval_lds<M, T, IPW, true, F_AX>(P, S, i, xh, P.dtau_h, S.W + i * P.Lp);
+  // cgmres.hpp:83-96: x_dxh, Fh = F(U, x_dxh, t+h), W = b.  Collective; ends with W published.
+  __device__ __forceinline__ void preamble() {
+    make_xh();  // read back by the same lanes only
+    f_eval<false, F_PLAIN>(S.xh, P.dtau_h, S.Fh, false);
+    __syncthreads();
+    f_eval<false, F_RHS>(S.xs, P.dtau_0, S.W, false);
+    __syncthreads();
+  }
+  // Ax_func in place on W (cgmres.hpp:164-175).  Collective; ends with W published.
+  __device__ __forceinline__ void ax(bool only_active) {
+    f_eval<true, F_AX>(S.xh, P.dtau_h, S.W, only_active);
+    __syncthreads();
   }
 
   // Gmres::gmres (gmres.hpp:28-112).  In: x (registers `xv`), b (registers `bb`), W = A*x0 already in LDS.
   // Out: xv updated.  All threads of the block must call this (it contains workgroup barriers).
   __device__ __forceinline__ void gmres(T* xv, const T* bb) {
-    const int L = P.L, kmax = P.kmax, k1 = kmax + 1;
+    const int kmax = P.kmax, k1 = kmax + 1;
     T* Hi = S.H + inst * P.Hp;
     T* rhoi = S.rho + inst * k1;
     T* gi = S.g + inst * 3 * kmax;
@@ -301,12 +353,12 @@ struct WgCtx {
     bool active = valid;
     // r0 = b - A x0 ; rho = ||r0||      gmres.hpp:33-37
     {
-      T ax[MAXM];
-      lds_to_reg(ax, S.W);
+      T ax0[MAXM];
+      lds_to_reg(ax0, S.W);
       T ss = 0;
 #pragma unroll
       for (int m = 0; m < MAXM; ++m) {
-        vcur[m] = bb[m] - ax[m];
+        vcur[m] = bb[m] - ax0[m];
         ss += vcur[m] * vcur[m];
       }
       const T rho0 = sqrt_t<T>(row16_sum(ss));
@@ -327,8 +379,7 @@ struct WgCtx {
     int k = 0;
     for (; k < kmax; ++k) {  // gmres.hpp:46
       if (!__syncthreads_or(active ? 1 : 0)) break;  // also publishes W / flag to the sweep lanes
-      ax_sweep(true);                                // :48  W <- A v_k, in place
-      __syncthreads();
+      ax(true);                                      // :48  W <- A v_k, in place
       if (active) {
         lds_to_reg(w, S.W);
         T* Hk = Hi + k1 * k;
@@ -450,7 +501,6 @@ struct WgCtx {
 #pragma unroll
       for (int m = 0; m < MAXM; ++m) xv[m] = xv[m] + acc[m];
     }
-    (void)L;
   }
 
   // status + small Krylov arrays of this row's instance -> HBM
@@ -480,14 +530,12 @@ __global__ __launch_bounds__(IPW * 16) void tick_wg_kernel(WgParams<T> P) {
   // H region zeroed so the exported Hessenberg has no stale entries
   for (int q = C.r; q < P.Hp; q += 16) C.S.H[C.inst * P.Hp + q] = T(0);
   __syncthreads();
-  C.preamble_sweeps();  // Fh, W = b
-  __syncthreads();
+  C.preamble();  // Fh, W = b
   C.lds_to_reg(bb, C.S.W);
   __syncthreads();
   C.reg_to_lds(C.S.W, du);  // direction of the first mat-vec: x0 = dUdt (warm start, cgmres.hpp:99)
   __syncthreads();
-  C.ax_sweep(false);  // W <- A dUdt
-  __syncthreads();
+  C.ax(false);  // W <- A dUdt
   C.gmres(du, bb);
   // U += dUdt*dt, u = U[0:dim_u]  (cgmres.hpp:102-109)
   T un[MAXM];
@@ -510,7 +558,7 @@ __global__ __launch_bounds__(IPW * 16) void tick_wg_kernel(WgParams<T> P) {
       for (int c = 0; c < M::NX; ++c) x[c] = C.S.xs[c * IPW + i];
 #pragma unroll
       for (int j = 0; j < M::NU; ++j) u[j] = C.S.U[i * P.Lp + j];
-      M::dxdt(f, x, u, tr);
+      M::dxdt(f, x, u, tr, C.mc);
 #pragma unroll
       for (int c = 0; c < M::NX; ++c) P.x_next[size_t(C.bi) * M::NX + c] = x[c] + f[c] * P.dt;
     }
@@ -545,12 +593,7 @@ __global__ __launch_bounds__(IPW * 16) void hook_wg_kernel(WgParams<T> P) {
     load_im(a, P.hook_in0);
     C.reg_to_lds(C.S.U, a);
     __syncthreads();
-    if (C.sweep_lane) {
-      T x[M::NX];
-#pragma unroll
-      for (int c = 0; c < M::NX; ++c) x[c] = C.S.xs[c * IPW + C.tid];
-      f_eval_lds<M, T, IPW, false, F_PLAIN>(P, C.S, C.tid, x, P.hook_dtau, C.S.W + C.tid * P.Lp);
-    }
+    C.template f_eval<false, F_PLAIN>(C.S.xs, P.hook_dtau, C.S.W, false);
     __syncthreads();
     C.lds_to_reg(a, C.S.W);
     store_im(P.hook_out, a);
@@ -559,8 +602,7 @@ __global__ __launch_bounds__(IPW * 16) void hook_wg_kernel(WgParams<T> P) {
   if (P.mode == WG_HOOK_PREPARE) {  // cgmres.hpp:83-96
     C.load_common(P.U);
     __syncthreads();
-    C.preamble_sweeps();
-    __syncthreads();
+    C.preamble();
     C.lds_to_reg(a, C.S.W);
     if (P.hook_out) store_im(P.hook_out, a);
     C.lds_to_reg(a, C.S.Fh);
@@ -576,8 +618,7 @@ __global__ __launch_bounds__(IPW * 16) void hook_wg_kernel(WgParams<T> P) {
   load_im(a, P.hook_in0);
   C.reg_to_lds(C.S.W, a);
   __syncthreads();
-  C.ax_sweep(false);
-  __syncthreads();
+  C.ax(false);
   if (P.mode == WG_HOOK_AX) {
     C.lds_to_reg(a, C.S.W);
     store_im(P.hook_out, a);

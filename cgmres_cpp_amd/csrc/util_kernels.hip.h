@@ -81,7 +81,9 @@ __global__ void newton_u0_kernel(T* __restrict__ u0, const T* __restrict__ x0, c
   for (int i = 0; i < NX; ++i) x[i] = x0[size_t(b) * NX + i];
   for (int j = 0; j < NU; ++j) u[j] = u0[size_t(b) * NU + j];
   for (int j = 0; j < NP; ++j) p[j] = p0[size_t(b) * NP + j];
-  M::dxdt(f, x, u, tr);  // only for the trig values dHdu reads (they depend on x alone)
+  typename M::Math mc;
+  mc.init();
+  M::dxdt(f, x, u, tr, mc);  // only for the trig values dHdu reads (they depend on x alone)
   M::dPhidx(l, x, p);
   for (int it = 0; it < n_loop; ++it) {
     M::dHdu(rhs, x, u, p, l, tr);
@@ -97,7 +99,9 @@ template <class M>
 __global__ void probe_kernel(const double* x, const double* u, const double* p, const double* l, double* out) {
   constexpr int NX = M::NX, NU = M::NU;
   double f[NX], g[NX], hx[NX], hu[NU], tr[M::NC > 0 ? M::NC : 1];
-  M::dxdt(f, x, u, tr);
+  typename M::Math mc;
+  mc.init();
+  M::dxdt(f, x, u, tr, mc);
   M::dPhidx(g, x, p);
   M::dHdx(hx, x, u, p, l, tr);
   M::dHdu(hu, x, u, p, l, tr);
