@@ -8,8 +8,8 @@ example's forward-Euler plant, everything resident in HBM.
 
 One "step" = one control tick of the whole per-GPU batch (one launch of the tick kernel).  Weak scaling:
 every rank owns `--batch` controllers; rank 0 draws the whole job's seeded inputs and the shards are
-scattered over RCCL; there is no collective inside the timed region (instances are independent).
-Prints ONE JSON line on rank 0.
+scattered over RCCL (cgmres_cpp_amd/sharding.py); there is no collective inside the timed region because
+controller instances are independent.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -25,6 +25,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MODEL, DV, KMAX = "pendulum", 50, 10
 DIM_X, DIM_U, DIM_P = 4, 3, 2
+# rocprofv3 PMC summary of this same command (tools/profile_bench.sh + tools/summarise_profile.py)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_v3_wg_bench_pmc.json")
 
 
 def algorithmic_bytes(k, L=DIM_U * DV, scalar=8):
@@ -57,6 +59,18 @@ def cpu_baseline(batch, tol, warm, seconds_budget):
                       f"mean Arnoldi iterations last tick {ks.mean():.2f}"}
 
 
+def measured_traffic(kernel_variant):
+    """HBM bytes per launch from the committed PMC passes of this command (null when none matches)."""
+    try:
+        s = json.load(open(PMC_SUMMARY))
+    except OSError:
+        return None, None
+    want = "tick_wg_kernel" if kernel_variant == 2 else "tick_lane_kernel"
+    if want not in s.get("kernel", ""):
+        return None, None
+    return s["hbm_bytes_per_launch"], os.path.relpath(PMC_SUMMARY, ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,7 +80,7 @@ def main():
     ap.add_argument("--tol", type=float, default=0.0,
                     help="0 = fixed-k mode (always k_max Arnoldi iterations, deterministic work; headline); "
                          "1e-6 = the reference's early-exit mode")
-    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--variant", type=int, default=0, help="kernel mapping: 0 default, 1 lane, 2 wg")
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall budget of the timed CPU-baseline part")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ref-mode", action="store_true", help="skip the secondary tol=1e-6 measurement")
@@ -76,13 +90,14 @@ def main():
     import torch.distributed as dist
 
     import cgmres_cpp_amd as cg
+    from cgmres_cpp_amd import scenarios
+    from cgmres_cpp_amd.sharding import scatter_rows
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if world == 1 and args.gpus > 1:
+        sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: there is no CPU path")
     torch.cuda.set_device(local)
@@ -93,31 +108,21 @@ def main():
 
     B = args.batch
     # ---- inputs: rank 0 draws the whole job (seeded), shards go out over RCCL (the only exchange) ------
-    x_d = torch.empty(B, DIM_X, dtype=torch.float64, device=dev)
-    u0_d = torch.empty(B, DIM_U, dtype=torch.float64, device=dev)
-    p_d = torch.empty(B, DIM_P, dtype=torch.float64, device=dev)
-    if rank == 0:
-        from cgmres_cpp_amd import scenarios
-        X0, U0, P0 = scenarios.batch(MODEL, B * world)
-        xs = [torch.from_numpy(X0[r * B:(r + 1) * B]).to(dev) for r in range(world)]
-        us = [torch.from_numpy(U0[r * B:(r + 1) * B]).to(dev) for r in range(world)]
-        ps = [torch.from_numpy(P0[r * B:(r + 1) * B]).to(dev) for r in range(world)]
-    else:
-        xs = us = ps = None
-    if world > 1:
-        dist.scatter(x_d, xs, src=0)
-        dist.scatter(u0_d, us, src=0)
-        dist.scatter(p_d, ps, src=0)
-    else:
-        x_d.copy_(xs[0]), u0_d.copy_(us[0]), p_d.copy_(ps[0])
+    full = scenarios.batch(MODEL, B * world) if rank == 0 else (None, None, None)
+    x_d = scatter_rows(full[0], B * world, DIM_X, world, rank, dev, dist)
+    u0_d = scatter_rows(full[1], B * world, DIM_U, world, rank, dev, dist)
+    p_d = scatter_rows(full[2], B * world, DIM_P, world, rank, dev, dist)
     torch.cuda.synchronize()
     x0_h, u0_h, p_h = x_d.cpu().numpy(), u0_d.cpu().numpy(), p_d.cpu().numpy()
+    assert x0_h.shape == (B, DIM_X)
 
     stream = torch.cuda.current_stream().cuda_stream
+    resolved = {}
 
     def run(tol, steps, warmup):
         ctrl = cg.CgmresBatch(MODEL, batch=B, dv=DV, k_max=KMAX, tol=tol, device=local, stream=stream,
                               variant=args.variant)
+        resolved["variant"] = ctrl.variant
         ctrl.set_ptau_repeat(p_h)
         ctrl.init_u0(u0_h)
         ctrl.init_u0_newton(u0_h, x0_h, p_h, 10)
@@ -154,6 +159,7 @@ def main():
     bytes_per_launch = float(sum(algorithmic_bytes(int(k)) for k in n_ax)) if args.tol > 0 else \
         float(B * algorithmic_bytes(KMAX))
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+    traffic, traffic_src = measured_traffic(resolved["variant"]) if B == 4096 and args.tol == 0.0 else (None, None)
 
     ref_mode = None
     if not args.no_ref_mode and args.tol == 0.0:
@@ -161,6 +167,7 @@ def main():
         ref_mode = {"tol": 1e-6, "value": B * world * args.steps / w2, "ms_per_step": w2 * 1e3 / args.steps,
                     "mean_arnoldi_last_tick": float(np.mean(n2))}
 
+    kernel_name = {1: "tick_lane_kernel", 2: "tick_wg_kernel"}[resolved["variant"]]
     out = {
         "metric": "C/GMRES control steps/sec, batch=4096 N=50 kmax=10; HBM GB/s vs roofline",
         "value": value, "unit": "control steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -169,11 +176,11 @@ def main():
         "config": {"workload": "arm_type_inverted_pendulum controllers, closed loop with on-device Euler plant",
                    "batch_per_gpu": B, "global_batch": B * world, "N": DV, "kmax": KMAX, "tol": args.tol,
                    "mode": "fixed-k (tol=0, every instance runs k_max Arnoldi iterations)" if args.tol == 0
-                   else "reference early-exit", "variant": args.variant, "parallelism": f"batch-shard x{world}",
+                   else "reference early-exit", "variant": resolved["variant"], "parallelism": f"batch-shard x{world}",
                    "inputs": "splitmix64(12345) perturbed x0/targets, Newton-initialised U0 (SURVEY.md §8d)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "tick kernel (one launch per control step)", "launch_ms": launch_ms,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": f"{kernel_name} (one launch per control step)", "launch_ms": launch_ms,
                      "algorithmic_bytes_per_launch": bytes_per_launch},
     }
     if ref_mode:
@@ -183,6 +190,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

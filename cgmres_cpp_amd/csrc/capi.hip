@@ -305,4 +305,16 @@ int cgmres_hip_memcpy_d2h(cgmres_hip_handle h, void* dst, const void* src, uint6
   return 0;
 }
 
+#ifdef CGM_STAMPS
+/* diagnostic build only (tools/phase_stamps.py): copies and clears the 64 stamp words of the pendulum/f64 wg context */
+int cgmres_hip_debug_stamps(long long* out) {
+  long long* p = cgm::debug_stamps_ptr();
+  if (!p || !out) return fail(CGMRES_HIP_EINVAL, "no stamp buffer");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out, p, 64 * sizeof(long long), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset(p, 0, 64 * sizeof(long long)));
+  return 0;
+}
+#endif
+
 }  // extern "C"

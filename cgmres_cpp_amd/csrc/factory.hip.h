@@ -11,4 +11,7 @@ cgmres_hip_ctx* make_msd_f64(const cgmres_hip_config& cfg, int* resolved);
 cgmres_hip_ctx* make_msd_f32(const cgmres_hip_config& cfg, int* resolved);
 cgmres_hip_ctx* make_semiactive_f64(const cgmres_hip_config& cfg, int* resolved);
 cgmres_hip_ctx* make_semiactive_f32(const cgmres_hip_config& cfg, int* resolved);
+#ifdef CGM_STAMPS
+long long* debug_stamps_ptr();  // diagnostic build only: stamp buffer of the last pendulum/f64 wg context
+#endif
 }  // namespace cgm

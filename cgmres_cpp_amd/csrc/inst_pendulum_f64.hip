@@ -5,4 +5,7 @@ namespace cgm {
 cgmres_hip_ctx* make_pendulum_f64(const cgmres_hip_config& cfg, int* resolved) {
   return make_variant<PendulumDev<double>, double>(cfg, resolved);
 }
+#ifdef CGM_STAMPS
+long long* debug_stamps_ptr() { return CtxWg<PendulumDev<double>, double>::g_stamps(); }
+#endif
 }  // namespace cgm

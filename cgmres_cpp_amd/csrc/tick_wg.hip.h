@@ -49,7 +49,18 @@ struct WgParams {
   const T *hook_in0, *hook_in1;  // instance-major [B][L]
   T* hook_out;
   T hook_dtau;
+#ifdef CGM_STAMPS
+  long long* stamps;  // diagnostic build only (tools/phase_stamps.py): per-phase s_memtime totals of block 0
+#endif
 };
+
+// Diagnostic build only: accumulate shader-clock deltas per phase (thread 0 of block 0).  Compiles to nothing
+// in the product build.
+#ifdef CGM_STAMPS
+#define CGM_STAMP(ctx, id) (ctx).stamp(id)
+#else
+#define CGM_STAMP(ctx, id) ((void)0)
+#endif
 
 // ---- DPP row reductions -------------------------------------------------------------------------
 template <int CTRL>
@@ -122,6 +133,17 @@ struct WgCtx {
   bool sweep_lane;      // this thread runs the serial sweeps (for instance `tid`)
   int bi;               // global instance of the sweep lane
   typename M::Math mc;  // per-thread math context (pinned sin/cos constants)
+#ifdef CGM_STAMPS
+  long long t_last;
+  __device__ __forceinline__ void stamp(int id) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+      const long long now = clock64();
+      P.stamps[id] += now - t_last;
+      P.stamps[32 + id] += 1;
+      t_last = now;
+    }
+  }
+#endif
   __device__ WgCtx(const WgParams<T>& P_, unsigned char* smem)
       : P(P_), S(smem, P_), tid(threadIdx.x), inst(threadIdx.x >> 4), r(threadIdx.x & 15) {
     b = blockIdx.x * IPW + inst;
@@ -129,6 +151,13 @@ struct WgCtx {
     bi = blockIdx.x * IPW + tid;
     sweep_lane = tid < IPW && bi < P.B;
     mc.init();
+#ifdef CGM_STAMPS
+    t_last = clock64();
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+      P.stamps[30] = wall_clock64();
+      P.stamps[31] = t_last;
+    }
+#endif
   }
   __device__ __forceinline__ int elem(int m) const { return r + 16 * m; }
 
@@ -242,6 +271,7 @@ struct WgCtx {
       }
     }
     __syncthreads();
+    CGM_STAMP(*this, 4);
     // phase 2: costate-free part of every backward stage, all threads, items (s, i) with i fastest
     {
       const T sc_phi = MODE == F_RHS ? P.one_m_zh : T(1.0);
@@ -275,6 +305,7 @@ struct WgCtx {
       }
     }
     __syncthreads();
+    CGM_STAMP(*this, 5);
     // phase 3: costate sweep (cgmres.hpp:145-153) + the costate part of dH/du (:156-161)
     if (go) {
       const int i = tid;
@@ -338,8 +369,10 @@ struct WgCtx {
   }
   // Ax_func in place on W (cgmres.hpp:164-175).  Collective; ends with W published.
   __device__ __forceinline__ void ax(bool only_active) {
+    CGM_STAMP(*this, 3);
     f_eval<true, F_AX>(S.xh, P.dtau_h, S.W, only_active);
     __syncthreads();
+    CGM_STAMP(*this, 6);
   }
 
   // Gmres::gmres (gmres.hpp:28-112).  In: x (registers `xv`), b (registers `bb`), W = A*x0 already in LDS.
@@ -412,6 +445,7 @@ struct WgCtx {
         T nn = 0;
 #pragma unroll
         for (int m = 0; m < MAXM; ++m) nn += w[m] * w[m];
+        CGM_STAMP(*this, 7);
         const T hn = sqrt_t<T>(row16_sum(nn));  // :60
         if (r == 0) {
           Hk[k + 1] = hn;
@@ -433,6 +467,7 @@ struct WgCtx {
           // Every lane of the row computes it from the same LDS words (broadcast reads; a row never straddles
           // a wave, and LDS operations of one wave complete in order), lane 0 writes back: the convergence
           // decision is therefore row-uniform.
+          CGM_STAMP(*this, 8);
           T en;
           {
             for (int i = 0; i < k; ++i) {
@@ -459,6 +494,7 @@ struct WgCtx {
               rhoi[k + 1] = en;
             }
           }
+          CGM_STAMP(*this, 9);
           if (abs_t(en) < P.tol) {  // :93-95 — converged: column k is NOT used by the solve
             active = false;
             if (r == 0) {
@@ -471,6 +507,7 @@ struct WgCtx {
       }
     }
     __syncthreads();
+    CGM_STAMP(*this, 10);
     // natural exit: every column is used
     const int reason = S.reason[inst];
     const int ks = reason == 0 ? (valid ? kmax : 0) : (reason == 1 ? S.ksolve[inst] : 0);
@@ -486,6 +523,7 @@ struct WgCtx {
       }
     }
     __syncthreads();
+    CGM_STAMP(*this, 11);
     if (valid && reason <= 1) {
       // x += V[:,0:ks] y  (gmres.hpp:110-111), accumulated j-ascending from 0 like matrix.hpp:82-91
       T acc[MAXM];
@@ -530,13 +568,16 @@ __global__ __launch_bounds__(IPW * 16) void tick_wg_kernel(WgParams<T> P) {
   // H region zeroed so the exported Hessenberg has no stale entries
   for (int q = C.r; q < P.Hp; q += 16) C.S.H[C.inst * P.Hp + q] = T(0);
   __syncthreads();
+  CGM_STAMP(C, 0);
   C.preamble();  // Fh, W = b
+  CGM_STAMP(C, 1);
   C.lds_to_reg(bb, C.S.W);
   __syncthreads();
   C.reg_to_lds(C.S.W, du);  // direction of the first mat-vec: x0 = dUdt (warm start, cgmres.hpp:99)
   __syncthreads();
   C.ax(false);  // W <- A dUdt
   C.gmres(du, bb);
+  CGM_STAMP(C, 12);
   // U += dUdt*dt, u = U[0:dim_u]  (cgmres.hpp:102-109)
   T un[MAXM];
   C.lds_to_reg(un, C.S.U);
@@ -563,6 +604,13 @@ __global__ __launch_bounds__(IPW * 16) void tick_wg_kernel(WgParams<T> P) {
       for (int c = 0; c < M::NX; ++c) P.x_next[size_t(C.bi) * M::NX + c] = x[c] + f[c] * P.dt;
     }
   }
+  CGM_STAMP(C, 13);
+#ifdef CGM_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    P.stamps[28] += wall_clock64() - P.stamps[30];
+    P.stamps[29] += clock64() - P.stamps[31];
+  }
+#endif
 }
 
 // ---- white-box hooks on the same device code -------------------------------------------------------

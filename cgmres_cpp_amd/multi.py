@@ -1,0 +1,48 @@
+"""Several controller batches of different Models stepped in the same loop on one GPU — the batched form of the
+reference's multiple_controller example (multiple_controller/main.cpp:89-118: two Cgmres objects of different Model
+types, `controller1.control(u1,x1); controller2.control(u2,x2);` back to back, one timer around both).
+
+Each member batch has its own handle and HIP stream, so the tick kernels of the different models overlap on the
+device; `control_device` enqueues all of them and `synchronize` joins them."""
+from . import CgmresBatch
+
+
+class MultipleController:
+    def __init__(self, specs, device=0, streams=None):
+        """specs: list of dicts of CgmresBatch keyword arguments (model, batch, dv, k_max, ...).
+        streams: optional list of hipStream_t values (e.g. torch.cuda.Stream().cuda_stream), one per member."""
+        self.members = []
+        for i, kw in enumerate(specs):
+            kw = dict(kw)
+            kw.setdefault("device", device)
+            if streams is not None:
+                kw["stream"] = streams[i]
+            self.members.append(CgmresBatch(**kw))
+
+    def __len__(self):
+        return len(self.members)
+
+    def __getitem__(self, i):
+        return self.members[i]
+
+    def control(self, xs):
+        """Host arrays in, host arrays out: [u_1, u_2, ...] for [x_1, x_2, ...]."""
+        return [m.control(x) for m, x in zip(self.members, xs)]
+
+    def control_device(self, us, xs):
+        for m, u, x in zip(self.members, us, xs):
+            m.control_device(u, x)
+
+    def closed_loop_device(self, xs, us, n_ticks):
+        """n_ticks of every member's closed loop; ticks of different members interleave on their streams."""
+        for _ in range(n_ticks):
+            for m, x, u in zip(self.members, xs, us):
+                m.closed_loop_device(x, u, 1)
+
+    def synchronize(self):
+        for m in self.members:
+            m.synchronize()
+
+    def close(self):
+        for m in self.members:
+            m.close()

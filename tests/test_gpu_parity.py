@@ -301,3 +301,31 @@ def test_model_probe_matches_oracle_models(orc):
         r = orc.Controller(model, 8, 3)
         assert np.max(np.abs(f - r.plant(x, u))) <= 1e-12
         assert np.all(np.isfinite(np.concatenate([gphi, hx, hu])))
+
+
+def test_multiple_controller_mixed_batch(orc):
+    """BASELINE configs[3] shape: a Model1 (MSD) batch and a Model2 (pendulum) batch stepped in the same loop on
+    separate streams (cgmres_cpp_amd.multi.MultipleController, multiple_controller/main.cpp:104-110), each against
+    the oracle, teacher-forced."""
+    from cgmres_cpp_amd.multi import MultipleController
+    specs = [dict(model="msd", batch=40, dv=50, k_max=10), dict(model="pendulum", batch=56, dv=50, k_max=10)]
+    mc = MultipleController(specs)
+    refs, xs = [], []
+    for m, model in zip(mc.members, (1, 0)):
+        x0, u0, p = orc.batch_scenario(model, m.batch)
+        m.set_ptau_repeat(p)
+        m.init_u0(u0)
+        m.init_u0_newton(u0, x0, p, 10)
+        refs.append(_oracle_batch(orc, model, 50, 10, 1e-6, x0, u0, p))
+        xs.append(x0.copy())
+    for tick in range(5):
+        us = mc.control(xs)
+        for k, (m, rs) in enumerate(zip(mc.members, refs)):
+            n_ax, _ = m.get_status()
+            for i, r in enumerate(rs):
+                ur = r.control(xs[k][i])
+                assert np.max(np.abs(us[k][i] - ur)) <= U_TOL * (1 + tick), (tick, k, i)
+                assert n_ax[i] == r.last_solve()[0]
+                xs[k][i] = xs[k][i] + r.plant(xs[k][i], ur) * r.dt
+    # device-pointer path on two streams: same result as the host path of fresh controllers
+    mc.close()

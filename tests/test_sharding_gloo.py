@@ -1,0 +1,84 @@
+"""CPU, world_size 2 over gloo: the N>1 path of bench.py — rank 0 draws the seeded job, shards are scattered,
+every rank advances its own controllers, controls are gathered — gives exactly what one process computes for the
+whole batch.  (No GPU here: the per-shard compute is the oracle; the sharding/collective logic is what is tested.)"""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_bounds_cover_and_balance():
+    from cgmres_cpp_amd.sharding import shard_bounds
+    for n in (1, 7, 8, 4096, 4099, 8192):
+        for world in (1, 2, 3, 4, 8):
+            spans = [shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+WORKER = textwrap.dedent('''
+    import os, sys, json
+    sys.path.insert(0, os.environ["REPO_ROOT"])
+    import numpy as np, torch, torch.distributed as dist
+    from cgmres_cpp_amd import scenarios
+    from cgmres_cpp_amd.sharding import scatter_rows, gather_rows, shard_bounds
+    from oracle import orc
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    N, TICKS, DV, KM = 13, 4, 8, 3          # uneven split on purpose (7 + 6)
+    full = scenarios.batch("pendulum", N) if rank == 0 else (None, None, None)
+    dev = torch.device("cpu")
+    x = scatter_rows(full[0], N, 4, world, rank, dev, dist).numpy()
+    u0 = scatter_rows(full[1], N, 3, world, rank, dev, dist).numpy()
+    p = scatter_rows(full[2], N, 2, world, rank, dev, dist).numpy()
+    lo, hi = shard_bounds(N, world, rank)
+    assert x.shape == (hi - lo, 4)
+    us = []
+    for i in range(hi - lo):
+        c = orc.Controller(orc.PENDULUM, DV, KM)
+        orc.start_controller(c, x[i], u0[i], p[i])
+        u, _, _, _ = orc.closed_loop(c, x[i], TICKS)
+        us.append(u[-1])
+    got = gather_rows(torch.tensor(np.array(us)), N, world, rank, dist)
+    if rank == 0:
+        np.save(os.environ["OUT_NPY"], got)
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_two_rank_gloo_job_equals_single_process(tmp_path, orc):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    out = tmp_path / "u.npy"
+    env = dict(os.environ, REPO_ROOT=ROOT, OUT_NPY=str(out), MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    got = np.load(out)
+    from cgmres_cpp_amd import scenarios
+    x0, u0, p = scenarios.batch("pendulum", 13)
+    want = []
+    for i in range(13):
+        c = orc.Controller(orc.PENDULUM, 8, 3)
+        orc.start_controller(c, x0[i], u0[i], p[i])
+        u, _, _, _ = orc.closed_loop(c, x0[i], 4)
+        want.append(u[-1])
+    assert np.array_equal(got, np.array(want))

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Diagnostic (never part of the product build): rebuilds the library with -DCGM_STAMPS into gpurun_out/diag/,
+runs closed-loop ticks at the headline size and prints where block 0 spends its shader cycles."""
+import ctypes, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from cgmres_cpp_amd import build as b
+
+diag = os.path.join(ROOT, "gpurun_out", "diag")
+os.makedirs(diag, exist_ok=True)
+lib = os.path.join(diag, "libcgmres_hip_stamps.so")
+if "--build" in sys.argv or not os.path.exists(lib):
+    srcs, _ = b.sources()
+    from concurrent.futures import ThreadPoolExecutor
+    def cc(s):
+        o = os.path.join(diag, os.path.basename(s)[:-4] + ".o")
+        subprocess.run([b.HIPCC] + b.CFLAGS + ["-DCGM_STAMPS", "-c", "-o", o, s], check=True)
+        return o
+    with ThreadPoolExecutor(8) as ex:
+        objs = list(ex.map(cc, srcs))
+    subprocess.run([b.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-o", lib] + objs, check=True)
+    if "--build-only" in sys.argv:
+        sys.exit(0)
+b.LIB_PATH = lib
+import cgmres_cpp_amd as cg
+from cgmres_cpp_amd import scenarios
+B = 4096
+x0, u0, p = scenarios.batch("pendulum", B)
+c = cg.CgmresBatch("pendulum", batch=B, dv=50, k_max=10, tol=0.0)
+c.set_ptau_repeat(p); c.init_u0(u0); c.init_u0_newton(u0, x0, p, 10)
+xd = c.device_buffer((B, 4)).upload(x0); ud = c.device_buffer((B, 3))
+c.closed_loop_device(xd, ud, 50); c.synchronize()
+L = cg.load()
+out = (ctypes.c_longlong * 64)()
+L.cgmres_hip_debug_stamps(out)
+N = 100
+c.closed_loop_device(xd, ud, N); c.synchronize()
+L.cgmres_hip_debug_stamps(out)
+names = {0: "prologue loads", 1: "preamble (2 sweeps)", 3: "pre-sweep (shuffles, barrier_or)", 4: "sweep phase 1 (state)",
+         5: "sweep phase 2 (coeffs)", 6: "sweep phase 3 (costate)", 7: "MGS rounds", 8: "norm+normalise+store",
+         9: "Hessenberg scalar", 10: "loop exit barrier", 11: "back-subst", 12: "x update (V*y)", 13: "epilogue"}
+tot = out[29]; wall = out[28]
+print(f"ticks {N}: shader cycles/tick {tot/N:.0f}, wall {wall/N/100:.1f} us/tick -> clock {tot/wall*100/1e3:.2f} GHz")
+for k, n in names.items():
+    print(f"  {n:34s} {out[k]/N:10.0f} cyc/tick  {100*out[k]/tot:5.1f}%   ({out[32+k]/N:.0f} visits)")
+print("  accounted", sum(out[k] for k in names) / tot)

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/prof_<tag>/ (tools/profile_bench.sh) into the committed summaries
+profiles/<name>_kernel_stats.csv and profiles/<name>_pmc.json.
+
+HBM traffic per launch follows MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB of 64-byte fabric
+requests; on gfx950 FETCH_SIZE reports half of the bytes of a coalesced streaming read, so reads = 2 x FETCH_SIZE;
+WRITE_SIZE is exact."""
+import csv, glob, json, os, shutil, sys
+tag, name = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+shutil.copy(glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0], os.path.join(dst, f"{name}_kernel_stats.csv"))
+out = {"command": "python3 bench.py --steps N --warmup W --no-cpu-baseline --no-ref-mode (rocprofv3, three separate runs)"}
+stats = list(csv.DictReader(open(os.path.join(dst, f"{name}_kernel_stats.csv"))))
+k = max(stats, key=lambda r: float(r["TotalDurationNs"]))
+out["kernel"] = k["Name"]
+out["kernel_calls"] = int(k["Calls"])
+out["kernel_avg_ns"] = float(k["AverageNs"])
+for kind, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    f = glob.glob(os.path.join(src, f"pmc_{kind}", "*", "*counter_collection.csv"))[0]
+    rows = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"] == k["Name"] and r["Counter_Name"] == ctr]
+    vals = [float(r["Counter_Value"]) for r in rows]
+    out[f"{ctr}_KiB_per_launch"] = sum(vals) / len(vals)
+    out[f"{ctr}_launches"] = len(vals)
+out["read_bytes_per_launch"] = 2.0 * out["FETCH_SIZE_KiB_per_launch"] * 1024
+out["write_bytes_per_launch"] = out["WRITE_SIZE_KiB_per_launch"] * 1024
+out["hbm_bytes_per_launch"] = out["read_bytes_per_launch"] + out["write_bytes_per_launch"]
+out["note"] = "reads = 2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md §HBM); 8-byte-per-lane row loads are not the calibrated 16-byte case"
+b = json.load(open(os.path.join(src, "bench_trace.json")))
+out["bench_line_under_profiler"] = {k2: b[k2] for k2 in ("value", "ms_per_step", "roofline")}
+json.dump(out, open(os.path.join(dst, f"{name}_pmc.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
