@@ -7,7 +7,7 @@
 
 namespace cgm {
 
-constexpr size_t kLdsLimit = 160 * 1024;  // gfx950: 160 KiB per workgroup
+constexpr size_t kLdsLimit = 160 * 1024 - 1024;  // gfx950: 160 KiB per workgroup, minus the kernels' small static LDS
 
 template <class T>
 __global__ void replicate_rows_im(T* __restrict__ dst, size_t dst_pitch, const T* __restrict__ src, int B, int n,

@@ -22,6 +22,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "dpp.hip.h"
+
 namespace cgm {
 
 // fp64 sin/cos for the horizon sweeps.  The device libm's sincos costs ~150 VALU instructions per call with
@@ -220,6 +222,68 @@ struct PendulumDev {
     const T n3 = l[3] + dtau * (l[1] - l[3] * C22);
     l[0] = n0, l[1] = n1, l[2] = n2, l[3] = n3;
   }
+  // --- state sweep over a DPP quad (fp64 only) -----------------------------------------------------------------
+  // With one wave per SIMD an fp64 op issues every ~8 cycles and the serial state sweep (2 sincos + ~17 flops per
+  // stage) is the longest phase of a tick.  Here the four lanes of a quad carry ONE instance: all four hold the same
+  // x, lane rho evaluates one of the four polynomial kernels {sin d, cos d, sin x1, cos x1} (d = x0 - x1) through a
+  // single instruction stream (per-lane coefficient sets, A + B*P form for both kernels), the sin/cos pair of an
+  // angle is exchanged with quad_perm[1,0,3,2] for the quadrant fix-up, and the trig-dependent part of dxdt[3]
+  //      A32 x2^2 sin d  +  (A32a x2 - A32b u0) cos d  +  A52 sin x1          (model.hpp:41, regrouped)
+  // is one multiply per lane + a quad sum, bit-identical in the four lanes, so x stays replicated without any
+  // broadcast.  30 fp64 ops per stage and lane instead of 51.  Stage table writes: lane 0 stores x(s), lanes 0,1,3
+  // store sin d, cos d, cos x1.
+  static constexpr bool HAS_QUAD_SWEEP = sizeof(T) == 8;
+  struct QuadLane {
+    T c1, c2, c3, c4, c5, c6;  // polynomial coefficients of this lane's kernel (sin: S1..S6, cos: C1..C6)
+    T mp, mq, mr, ms;          // this lane's weight  (mp*x2 + mq)*x2 + (mr*u0 + ms)  of its trig value in dxdt[3]
+    bool is_cos, second_angle;
+    int trig_slot;             // stage-table slot of this lane's value (-1: not stored)
+    __device__ __forceinline__ void init(int rho, const Math& mc) {
+      is_cos = rho & 1, second_angle = rho >= 2;
+      c1 = is_cos ? mc.C1 : mc.S1, c2 = is_cos ? mc.C2 : mc.S2, c3 = is_cos ? mc.C3 : mc.S3;
+      c4 = is_cos ? mc.C4 : mc.S4, c5 = is_cos ? mc.C5 : mc.S5, c6 = is_cos ? mc.C6 : mc.S6;
+      mp = rho == 0 ? A32 : T(0), mq = rho == 1 ? A32a : T(0), mr = rho == 1 ? -A32b : T(0), ms = rho == 2 ? A52 : T(0);
+      trig_slot = rho == 0 ? NX : (rho == 1 ? NX + 1 : (rho == 3 ? NX + 2 : -1));
+    }
+  };
+  // One stage: x (replicated) -> x + dtau*dxdt(x, u0); returns this lane's trig value in *val.
+  static __device__ __forceinline__ void quad_stage(T* x, T u0, T dtau, const QuadLane& Q, const Math& mc, T* val) {
+    const T arg = Q.second_angle ? x[1] : x[0] - x[1];
+    T v;
+    if (__builtin_expect(__any(!(__builtin_fabs(arg) < T(1.0e5))), 0)) {  // rare: library path (also NaN)
+      double sn, cs;
+      ::sincos(double(arg), &sn, &cs);
+      v = Q.is_cos ? T(cs) : T(sn);
+    } else {
+      const T n = __builtin_rint(arg * mc.inv_pio2);
+      T r = __builtin_fma(-n, mc.pio2_hi, arg);
+      r = __builtin_fma(-n, mc.pio2_lo, r);
+      const int q = static_cast<int>(n);
+      const T z = r * r;
+      T P = fma3(z, Q.c6, Q.c5);
+      P = fma3(z, P, Q.c4);
+      P = fma3(z, P, Q.c3);
+      P = fma3(z, P, Q.c2);
+      P = fma3(z, P, Q.c1);
+      const T w = __builtin_fma(T(-0.5), z, T(1.0));
+      const T t = Q.is_cos ? z : r;   // sin: r + (z r) P      cos: (1 - z/2) + (z z) P
+      const T a = Q.is_cos ? w : r;
+      const T mine = fma3(z * t, P, a);
+      const T other = dpp_move<DPP_QUAD_SWAP1>(mine);  // the cos kernel of my angle if I am the sin lane, and v.v.
+      const T pick = (q & 1) ? other : mine;            // sin = {s,c,-s,-c}[q&3], cos = {c,-s,-c,s}[q&3]
+      const int flip = ((q + (Q.is_cos ? 1 : 0)) & 2) << 30;
+      v = __hiloint2double(__double2hiint(pick) ^ flip, __double2loint(pick));
+    }
+    *val = v;
+    const T m = __builtin_fma(__builtin_fma(Q.mp, x[2], Q.mq), x[2], __builtin_fma(Q.mr, u0, Q.ms));
+    const T trig_sum = quad_sum(m * v);
+    const T f3 = __builtin_fma(C22, x[2] - x[3], trig_sum);
+    const T f2 = __builtin_fma(-As, x[2], Bs * u0);
+    x[0] = __builtin_fma(dtau, x[2], x[0]);
+    x[1] = __builtin_fma(dtau, x[3], x[1]);
+    x[2] = __builtin_fma(dtau, f2, x[2]);
+    x[3] = __builtin_fma(dtau, f3, x[3]);
+  }
   static __device__ __forceinline__ void ddHduu(T* m, const T*, const T* u, const T*, const T*) {  // :64-76
     m[0] = r0 + 2 * u[2];
     m[1] = 0;
@@ -274,6 +338,7 @@ struct MsdDev {
     g[4] = (u[0] - uc) * (u[0] - uc) + u[2] * u[2] - ur * ur;
     g[5] = (u[1] - uc) * (u[1] - uc) + u[3] * u[3] - ur * ur;
   }
+  static constexpr bool HAS_QUAD_SWEEP = false;  // no transcendental in the state equation: nothing to spread
   // affine-in-costate split (model.hpp:50-64 regrouped): the Jacobian is constant, only qx depends on the stage
   static constexpr int NBW = 4, NUL = 2;
   static __device__ __forceinline__ void stage_coeffs(T* bw, T* phi, const T* x, const T* u, const T* p, const T*,
@@ -346,6 +411,7 @@ struct SemiactiveDev {
     g[1] = -r1 + 2 * u[1] * u[2];
     g[2] = (u[0] - uc) * (u[0] - uc) + u[1] * u[1] - ur * ur;
   }
+  static constexpr bool HAS_QUAD_SWEEP = false;
   // affine-in-costate split (model.hpp:46-55 regrouped)
   static constexpr int NBW = 4, NUL = 1;
   static __device__ __forceinline__ void stage_coeffs(T* bw, T* phi, const T* x, const T* u, const T*, const T*,

@@ -26,6 +26,7 @@
 
 #include <cfloat>
 
+#include "dpp.hip.h"
 #include "models.hip.h"
 #include "tick_lane.hip.h"  // sqrt_t / abs_t / FOut
 
@@ -62,43 +63,18 @@ struct WgParams {
 #define CGM_STAMP(ctx, id) ((void)0)
 #endif
 
-// ---- DPP row reductions -------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ double dpp_move(double x) {
-  int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-template <int CTRL>
-__device__ __forceinline__ float dpp_move(float x) {
-  int v = __float_as_int(x);
-  v = __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
-  return __int_as_float(v);
-}
-// Sum over the 16 lanes of a DPP row; every lane receives the same bits (each step adds the two
-// operands of a commutative pair).
-template <class T>
-__device__ __forceinline__ T row16_sum(T x) {
-  x += dpp_move<0xB1>(x);   // quad_perm [1,0,3,2]
-  x += dpp_move<0x4E>(x);   // quad_perm [2,3,0,1]
-  x += dpp_move<0x141>(x);  // row_half_mirror
-  x += dpp_move<0x140>(x);  // row_mirror
-  return x;
-}
-
 // ---- LDS carve-up -------------------------------------------------------------------------------
 template <class M, class T, int IPW>
 struct WgLds {
   // stage table: NSTG values per (stage, instance), layout [stage][slot][IPW]
   //   after phase 1: slots 0..NX-1 = x(s), NX..NX+NC-1 = trig(s);  after phase 2: slots 0..NBW-1 = costate coefficients
   static constexpr int NSTG = (M::NX + M::NC) > M::NBW ? (M::NX + M::NC) : M::NBW;
-  T *U, *Fh, *W, *R, *p, *H, *rho, *g, *xs, *xh;
+  T *U, *Fh, *W, *R, *p, *H, *rho, *g, *xs, *xh, *xT;  // xT: terminal state of the last state sweep
   int *flag, *reason, *nax, *ksolve;
   static __host__ __device__ size_t count_T(int dv, int kmax, int Lp, int Pp, int Hp) {
     const int k1 = kmax + 1;
     return size_t(3) * IPW * Lp + size_t(dv) * NSTG * IPW + size_t(IPW) * Pp + size_t(IPW) * Hp + size_t(IPW) * k1 +
-           size_t(IPW) * 3 * kmax + size_t(2) * M::NX * IPW;
+           size_t(IPW) * 3 * kmax + size_t(3) * M::NX * IPW;
   }
   static __host__ __device__ size_t bytes(int dv, int kmax, int Lp, int Pp, int Hp) {
     return count_T(dv, kmax, Lp, Pp, Hp) * sizeof(T) + 4 * IPW * sizeof(int) + 16;
@@ -116,6 +92,7 @@ struct WgLds {
     g = q, q += IPW * 3 * P.kmax;
     xs = q, q += M::NX * IPW;
     xh = q, q += M::NX * IPW;
+    xT = q, q += M::NX * IPW;
     int* z = reinterpret_cast<int*>(q);
     flag = z, reason = z + IPW, nax = z + 2 * IPW, ksolve = z + 3 * IPW;
   }
@@ -244,13 +221,42 @@ struct WgCtx {
     constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC, NBW = M::NBW, NUL = M::NUL;
     const int dv = P.dv;
     const bool go = sweep_lane && (!only_active || S.flag[tid]);
-    T xs[NX];
-    // phase 1: state sweep, cgmres.hpp:132-140
-    if (go) {
+    // phase 1: state sweep, cgmres.hpp:132-140; leaves x(dv) in S.xT
+    if constexpr (M::HAS_QUAD_SWEEP) {
+      // four lanes (one DPP quad) per instance — see PendulumDev::quad_stage
+      const int qi = tid >> 2, rho = tid & 3;
+      const bool goq = tid < 4 * IPW && blockIdx.x * IPW + qi < P.B && (!only_active || S.flag[qi]);
+      if (goq) {
+        typename M::QuadLane Q;
+        Q.init(rho, mc);
+        const T* __restrict__ U = S.U + qi * P.Lp;
+        const T* W = S.W + qi * P.Lp;
+        T* __restrict__ R = S.R + qi;
+        T x[NX];
+#pragma unroll
+        for (int c = 0; c < NX; ++c) x[c] = x0c[c * IPW + qi];
+        for (int s = 0; s < dv; ++s) {
+          T u0 = U[s * NU];
+          if (PERT) u0 = W[s * NU] * P.h + u0;
+          if (rho == 0) {
+#pragma unroll
+            for (int c = 0; c < NX; ++c) R[(s * NSTG + c) * IPW] = x[c];
+          }
+          T val;
+          M::quad_stage(x, u0, dtau, Q, mc, &val);
+          if (Q.trig_slot >= 0) R[(s * NSTG + Q.trig_slot) * IPW] = val;
+        }
+        if (rho == 0) {
+#pragma unroll
+          for (int c = 0; c < NX; ++c) S.xT[c * IPW + qi] = x[c];
+        }
+      }
+    } else if (go) {
       const int i = tid;
       const T* __restrict__ U = S.U + i * P.Lp;
       const T* W = S.W + i * P.Lp;
       T* __restrict__ R = S.R + i;
+      T xs[NX];
 #pragma unroll
       for (int c = 0; c < NX; ++c) xs[c] = x0c[c * IPW + i];
       for (int s = 0; s < dv; ++s) {
@@ -269,6 +275,8 @@ struct WgCtx {
 #pragma unroll
         for (int c = 0; c < NX; ++c) xs[c] = f[c] * dtau + xs[c];
       }
+#pragma unroll
+      for (int c = 0; c < NX; ++c) S.xT[c * IPW + i] = xs[c];
     }
     __syncthreads();
     CGM_STAMP(*this, 4);
@@ -310,7 +318,9 @@ struct WgCtx {
     if (go) {
       const int i = tid;
       const T sc = MODE == F_PLAIN ? T(1.0) : (MODE == F_RHS ? P.one_m_zh * P.inv_h : P.inv_h);
-      T l[NX], p[NP > 0 ? NP : 1];
+      T l[NX], xs[NX], p[NP > 0 ? NP : 1];
+#pragma unroll
+      for (int c = 0; c < NX; ++c) xs[c] = S.xT[c * IPW + i];
 #pragma unroll
       for (int j = 0; j < NP; ++j) p[j] = S.p[i * P.Pp + dv * NP + j];
       M::dPhidx(l, xs, p);
