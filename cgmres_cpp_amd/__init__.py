@@ -51,7 +51,8 @@ _lib = None
 
 
 def lib_path():
-    return _build.LIB_PATH
+    """The in-tree library; CGMRES_HIP_LIB overrides it (A/B builds of the kernels, tools/ab_build.py)."""
+    return os.environ.get("CGMRES_HIP_LIB") or _build.LIB_PATH
 
 
 def load():

@@ -109,14 +109,15 @@ struct WgCtx {
   bool valid;           // row has a real instance
   bool sweep_lane;      // this thread runs the serial sweeps (for instance `tid`)
   int bi;               // global instance of the sweep lane
-  typename M::Math mc;  // per-thread math context (pinned sin/cos constants)
+  typename M::Math mc;  // per-thread math context (pinned sin/cos constants); A/B: keeping it live for the whole
+                        // kernel is 13 us/tick FASTER than re-creating it inside every sweep
 #ifdef CGM_STAMPS
   long long t_last;
   __device__ __forceinline__ void stamp(int id) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
       const long long now = clock64();
-      P.stamps[id] += now - t_last;
-      P.stamps[32 + id] += 1;
+      atomicAdd(reinterpret_cast<unsigned long long*>(&P.stamps[id]), (unsigned long long)(now - t_last));  // no-return
+      atomicAdd(reinterpret_cast<unsigned long long*>(&P.stamps[32 + id]), 1ull);
       t_last = now;
     }
   }
@@ -194,13 +195,30 @@ struct WgCtx {
     }
   }
 
-  // Common prologue: U, ptau -> LDS; x -> LDS (component-major); flags cleared.
+  // Common prologue: U, ptau -> LDS; x -> LDS (component-major); flags cleared.  All global loads of the row are
+  // issued before the first LDS store so they overlap (one HBM/L2 round trip instead of one per element).
   __device__ __forceinline__ void load_common(const T* Ug) {
-    load_row_to_lds(S.U, Ug);
+    constexpr int PMAX = 8;  // ptau entries per lane held in flight (covers dim_p*(dv+1) <= 128)
+    const int np_all = M::NP * (P.dv + 1);
+    T ureg[MAXM], preg[PMAX], xreg = T(0);
+    load_row_to_reg(ureg, Ug, P.Lg);
     if (valid) {
-      const int np_all = M::NP * (P.dv + 1);
-      for (int q = r; q < np_all; q += 16) S.p[inst * P.Pp + q] = P.ptau[size_t(b) * np_all + q];
-      if (r < M::NX) S.xs[r * IPW + inst] = P.x_in ? P.x_in[size_t(b) * M::NX + r] : T(0);
+#pragma unroll
+      for (int n = 0; n < PMAX; ++n) {
+        const int q = r + 16 * n;
+        preg[n] = q < np_all ? P.ptau[size_t(b) * np_all + q] : T(0);
+      }
+      if (r < M::NX && P.x_in) xreg = P.x_in[size_t(b) * M::NX + r];
+    }
+    if (valid) {
+      reg_to_lds(S.U, ureg);
+#pragma unroll
+      for (int n = 0; n < PMAX; ++n) {
+        const int q = r + 16 * n;
+        if (q < np_all) S.p[inst * P.Pp + q] = preg[n];
+      }
+      for (int q = r + 16 * PMAX; q < np_all; q += 16) S.p[inst * P.Pp + q] = P.ptau[size_t(b) * np_all + q];
+      if (r < M::NX) S.xs[r * IPW + inst] = xreg;
     }
     if (r == 0) {
       S.flag[inst] = 0;
@@ -393,6 +411,14 @@ struct WgCtx {
     T* rhoi = S.rho + inst * k1;
     T* gi = S.g + inst * 3 * kmax;
     T vcur[MAXM], w[MAXM];
+    // Ring of NBUF register buffers for the older basis vectors: NBUF rows are requested before the sweep starts, and
+    // every buffer is refilled with row i+NBUF as soon as round i has consumed it, so each load has NBUF-1 rounds
+    // (~1000 cycles) to arrive.  Static buffer indices: NGEN generations x NBUF buffers, fully unrolled.
+#ifndef CGM_AB_NBUF
+#define CGM_AB_NBUF 4
+#endif
+    constexpr int NBUF = MAXM <= 10 ? CGM_AB_NBUF : 2, NGEN = 12 / NBUF;
+    const bool preload = kmax <= NBUF * NGEN;  // workgroup-uniform; longer bases use the plain streaming loop
     bool active = valid;
     // r0 = b - A x0 ; rho = ||r0||      gmres.hpp:33-37
     {
@@ -422,26 +448,19 @@ struct WgCtx {
     int k = 0;
     for (; k < kmax; ++k) {  // gmres.hpp:46
       if (!__syncthreads_or(active ? 1 : 0)) break;  // also publishes W / flag to the sweep lanes
-      ax(true);                                      // :48  W <- A v_k, in place
+      // The first basis vectors this iteration needs are requested from HBM/L2 NOW: they arrive while wave 0 sweeps.
+      T vbuf[NBUF][MAXM];
+      if (preload && active) {
+#pragma unroll
+        for (int i = 0; i < NBUF; ++i)
+          if (i < k) load_vec(vbuf[i], vrow(i));
+      }
+      ax(true);  // :48  W <- A v_k, in place
       if (active) {
         lds_to_reg(w, S.W);
         T* Hk = Hi + k1 * k;
-        // modified Gram-Schmidt, gmres.hpp:52-58 — v_k is still in registers, older vectors stream from HBM/L2
-        T vi[MAXM];
-        if (k == 0) {
-#pragma unroll
-          for (int m = 0; m < MAXM; ++m) vi[m] = vcur[m];
-        } else {
-          load_vec(vi, vrow(0));
-        }
-        for (int i = 0; i <= k; ++i) {
-          T vn[MAXM];
-          if (i + 1 < k) {
-            load_vec(vn, vrow(i + 1));
-          } else {
-#pragma unroll
-            for (int m = 0; m < MAXM; ++m) vn[m] = vcur[m];
-          }
+        // modified Gram-Schmidt, gmres.hpp:52-58, in order; v_k itself is still in registers
+        auto mgs_round = [&](const T* vi, int i) {
           T part = 0;
 #pragma unroll
           for (int m = 0; m < MAXM; ++m) part += vi[m] * w[m];
@@ -449,9 +468,30 @@ struct WgCtx {
 #pragma unroll
           for (int m = 0; m < MAXM; ++m) w[m] = w[m] - vi[m] * hik;
           if (r == 0) Hk[i] = hik;
+        };
+        if (preload) {
 #pragma unroll
-          for (int m = 0; m < MAXM; ++m) vi[m] = vn[m];
+          for (int gen = 0; gen < NGEN; ++gen) {
+#pragma unroll
+            for (int bi = 0; bi < NBUF; ++bi) {
+              const int i = gen * NBUF + bi;
+              if (i < k) {
+                mgs_round(vbuf[bi], i);
+                if (i + NBUF < k) load_vec(vbuf[bi], vrow(i + NBUF));
+              }
+            }
+          }
+        } else {
+          T vi[MAXM], vn[MAXM];
+          if (k > 0) load_vec(vi, vrow(0));
+          for (int i = 0; i < k; ++i) {
+            if (i + 1 < k) load_vec(vn, vrow(i + 1));
+            mgs_round(vi, i);
+#pragma unroll
+            for (int m = 0; m < MAXM; ++m) vi[m] = vn[m];
+          }
         }
+        mgs_round(vcur, k);
         T nn = 0;
 #pragma unroll
         for (int m = 0; m < MAXM; ++m) nn += w[m] * w[m];
@@ -539,12 +579,32 @@ struct WgCtx {
       T acc[MAXM];
 #pragma unroll
       for (int m = 0; m < MAXM; ++m) acc[m] = T(0.0);
-      for (int j = 0; j < ks; ++j) {
-        T vj[MAXM];
-        load_vec(vj, vrow(j));
-        const T yj = rhoi[j];
+      if (preload) {  // same register ring as the Gram-Schmidt rounds
+        T vbuf[NBUF][MAXM];
 #pragma unroll
-        for (int m = 0; m < MAXM; ++m) acc[m] += vj[m] * yj;
+        for (int j = 0; j < NBUF; ++j)
+          if (j < ks) load_vec(vbuf[j], vrow(j));
+#pragma unroll
+        for (int gen = 0; gen < NGEN; ++gen) {
+#pragma unroll
+          for (int bi = 0; bi < NBUF; ++bi) {
+            const int j = gen * NBUF + bi;
+            if (j < ks) {
+              const T yj = rhoi[j];
+#pragma unroll
+              for (int m = 0; m < MAXM; ++m) acc[m] += vbuf[bi][m] * yj;
+              if (j + NBUF < ks) load_vec(vbuf[bi], vrow(j + NBUF));
+            }
+          }
+        }
+      } else {
+        for (int j = 0; j < ks; ++j) {
+          T vj[MAXM];
+          load_vec(vj, vrow(j));
+          const T yj = rhoi[j];
+#pragma unroll
+          for (int m = 0; m < MAXM; ++m) acc[m] += vj[m] * yj;
+        }
       }
 #pragma unroll
       for (int m = 0; m < MAXM; ++m) xv[m] = xv[m] + acc[m];
@@ -569,7 +629,7 @@ struct WgCtx {
 
 // ---- the tick kernel: cgmres.hpp:78-110 for IPW instances ----------------------------------------
 template <class M, class T, int IPW, int MAXM>
-__global__ __launch_bounds__(IPW * 16) void tick_wg_kernel(WgParams<T> P) {
+__global__ __launch_bounds__(IPW * 16) __attribute__((amdgpu_waves_per_eu(1, 1))) void tick_wg_kernel(WgParams<T> P) {
   extern __shared__ __align__(16) unsigned char smem[];
   WgCtx<M, T, IPW, MAXM> C(P, smem);
   T du[MAXM], bb[MAXM];
@@ -625,7 +685,7 @@ __global__ __launch_bounds__(IPW * 16) void tick_wg_kernel(WgParams<T> P) {
 
 // ---- white-box hooks on the same device code -------------------------------------------------------
 template <class M, class T, int IPW, int MAXM>
-__global__ __launch_bounds__(IPW * 16) void hook_wg_kernel(WgParams<T> P) {
+__global__ __launch_bounds__(IPW * 16) __attribute__((amdgpu_waves_per_eu(1, 1))) void hook_wg_kernel(WgParams<T> P) {
   extern __shared__ __align__(16) unsigned char smem[];
   WgCtx<M, T, IPW, MAXM> C(P, smem);
   T a[MAXM], c2[MAXM];

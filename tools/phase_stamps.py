@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 from cgmres_cpp_amd import build as b
 
-diag = os.path.join(ROOT, "gpurun_out", "diag")
+diag = os.path.join(ROOT, "_diag")  # git-ignored, but travels with gpurun (gpurun_out/ does not)
 os.makedirs(diag, exist_ok=True)
 lib = os.path.join(diag, "libcgmres_hip_stamps.so")
 if "--build" in sys.argv or not os.path.exists(lib):
