@@ -246,35 +246,41 @@ struct PendulumDev {
       trig_slot = rho == 0 ? NX : (rho == 1 ? NX + 1 : (rho == 3 ? NX + 2 : -1));
     }
   };
-  // One stage: x (replicated) -> x + dtau*dxdt(x, u0); returns this lane's trig value in *val.
-  static __device__ __forceinline__ void quad_stage(T* x, T u0, T dtau, const QuadLane& Q, const Math& mc, T* val) {
+  // The stage is split in two so the sweep loop can overlap consecutive stages: fp64 ops have an 8-cycle dependent
+  // latency but issue every ~4.4 cycles (tools/ubench_fp64.hip), and the angles of stage s+1 depend on x3(s) only
+  // through x1(s+1) = x1(s) + dtau*x3(s), not on dxdt[3](s).  quad_trig(x) is the long chain (reduction, Horner,
+  // quadrant fix-up); quad_advance(x, v) consumes its result.  Both are branch-free: arguments outside the fast range
+  // only set *bad, and the caller redoes the sweep with SLOW = true (library sin/cos) in that case.
+  template <bool SLOW>
+  static __device__ __forceinline__ T quad_trig(const T* x, const QuadLane& Q, const Math& mc, bool* bad) {
     const T arg = Q.second_angle ? x[1] : x[0] - x[1];
-    T v;
-    if (__builtin_expect(__any(!(__builtin_fabs(arg) < T(1.0e5))), 0)) {  // rare: library path (also NaN)
+    if (SLOW) {
       double sn, cs;
       ::sincos(double(arg), &sn, &cs);
-      v = Q.is_cos ? T(cs) : T(sn);
-    } else {
-      const T n = __builtin_rint(arg * mc.inv_pio2);
-      T r = __builtin_fma(-n, mc.pio2_hi, arg);
-      r = __builtin_fma(-n, mc.pio2_lo, r);
-      const int q = static_cast<int>(n);
-      const T z = r * r;
-      T P = fma3(z, Q.c6, Q.c5);
-      P = fma3(z, P, Q.c4);
-      P = fma3(z, P, Q.c3);
-      P = fma3(z, P, Q.c2);
-      P = fma3(z, P, Q.c1);
-      const T w = __builtin_fma(T(-0.5), z, T(1.0));
-      const T t = Q.is_cos ? z : r;   // sin: r + (z r) P      cos: (1 - z/2) + (z z) P
-      const T a = Q.is_cos ? w : r;
-      const T mine = fma3(z * t, P, a);
-      const T other = dpp_move<DPP_QUAD_SWAP1>(mine);  // the cos kernel of my angle if I am the sin lane, and v.v.
-      const T pick = (q & 1) ? other : mine;            // sin = {s,c,-s,-c}[q&3], cos = {c,-s,-c,s}[q&3]
-      const int flip = ((q + (Q.is_cos ? 1 : 0)) & 2) << 30;
-      v = __hiloint2double(__double2hiint(pick) ^ flip, __double2loint(pick));
+      return Q.is_cos ? T(cs) : T(sn);
     }
-    *val = v;
+    *bad = *bad || !(__builtin_fabs(arg) < T(1.0e5));  // also NaN
+    const T n = __builtin_rint(arg * mc.inv_pio2);
+    T r = __builtin_fma(-n, mc.pio2_hi, arg);
+    r = __builtin_fma(-n, mc.pio2_lo, r);
+    const int q = static_cast<int>(n);
+    const T z = r * r;
+    T P = fma3(z, Q.c6, Q.c5);
+    P = fma3(z, P, Q.c4);
+    P = fma3(z, P, Q.c3);
+    P = fma3(z, P, Q.c2);
+    P = fma3(z, P, Q.c1);
+    const T w = __builtin_fma(T(-0.5), z, T(1.0));
+    const T t = Q.is_cos ? z : r;  // sin: r + (z r) P      cos: (1 - z/2) + (z z) P
+    const T a = Q.is_cos ? w : r;
+    const T mine = fma3(z * t, P, a);
+    const T other = dpp_move<DPP_QUAD_SWAP1>(mine);  // the cos kernel of my angle if I am the sin lane, and v.v.
+    const T pick = (q & 1) ? other : mine;            // sin = {s,c,-s,-c}[q&3], cos = {c,-s,-c,s}[q&3]
+    const int flip = ((q + (Q.is_cos ? 1 : 0)) & 2) << 30;
+    return __hiloint2double(__double2hiint(pick) ^ flip, __double2loint(pick));
+  }
+  // x (replicated in the quad) -> x + dtau*dxdt(x, u0), v = this lane's trig value of the CURRENT x
+  static __device__ __forceinline__ void quad_advance(T* x, T u0, T dtau, T v, const QuadLane& Q) {
     const T m = __builtin_fma(__builtin_fma(Q.mp, x[2], Q.mq), x[2], __builtin_fma(Q.mr, u0, Q.ms));
     const T trig_sum = quad_sum(m * v);
     const T f3 = __builtin_fma(C22, x[2] - x[3], trig_sum);

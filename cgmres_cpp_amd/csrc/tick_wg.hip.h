@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
+#include <type_traits>
 
 #include "dpp.hip.h"
 #include "models.hip.h"
@@ -251,19 +252,28 @@ struct WgCtx {
         const T* W = S.W + qi * P.Lp;
         T* __restrict__ R = S.R + qi;
         T x[NX];
+        // one branch-free block per stage: store x(s) and its trig value, advance to x(s+1), start the trig of
+        // stage s+1 — the scheduler overlaps the trig chain of s+1 with the dxdt[3] chain of s
+        auto sweep = [&](auto slow_tag) -> bool {
+          constexpr bool SLOW = decltype(slow_tag)::value;
+          bool bad = false;
 #pragma unroll
-        for (int c = 0; c < NX; ++c) x[c] = x0c[c * IPW + qi];
-        for (int s = 0; s < dv; ++s) {
-          T u0 = U[s * NU];
-          if (PERT) u0 = W[s * NU] * P.h + u0;
-          if (rho == 0) {
+          for (int c = 0; c < NX; ++c) x[c] = x0c[c * IPW + qi];
+          T v = M::template quad_trig<SLOW>(x, Q, mc, &bad);
+          for (int s = 0; s < dv; ++s) {
+            T u0 = U[s * NU];
+            if (PERT) u0 = W[s * NU] * P.h + u0;
+            if (rho == 0) {
 #pragma unroll
-            for (int c = 0; c < NX; ++c) R[(s * NSTG + c) * IPW] = x[c];
+              for (int c = 0; c < NX; ++c) R[(s * NSTG + c) * IPW] = x[c];
+            }
+            if (Q.trig_slot >= 0) R[(s * NSTG + Q.trig_slot) * IPW] = v;
+            M::quad_advance(x, u0, dtau, v, Q);
+            v = M::template quad_trig<SLOW>(x, Q, mc, &bad);
           }
-          T val;
-          M::quad_stage(x, u0, dtau, Q, mc, &val);
-          if (Q.trig_slot >= 0) R[(s * NSTG + Q.trig_slot) * IPW] = val;
-        }
+          return bad;
+        };
+        if (__builtin_expect(__any(sweep(std::false_type{})), 0)) sweep(std::true_type{});
         if (rho == 0) {
 #pragma unroll
           for (int c = 0; c < NX; ++c) S.xT[c * IPW + qi] = x[c];
@@ -415,7 +425,7 @@ struct WgCtx {
     // every buffer is refilled with row i+NBUF as soon as round i has consumed it, so each load has NBUF-1 rounds
     // (~1000 cycles) to arrive.  Static buffer indices: NGEN generations x NBUF buffers, fully unrolled.
 #ifndef CGM_AB_NBUF
-#define CGM_AB_NBUF 4
+#define CGM_AB_NBUF 3
 #endif
     constexpr int NBUF = MAXM <= 10 ? CGM_AB_NBUF : 2, NGEN = 12 / NBUF;
     const bool preload = kmax <= NBUF * NGEN;  // workgroup-uniform; longer bases use the plain streaming loop
