@@ -13,14 +13,16 @@ constexpr int DPP_ROW_MIRROR = 0x140;
 template <int CTRL>
 __device__ __forceinline__ double dpp_move(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  // all lanes of the row are active wherever this is used and every control below reads a valid lane, so the
+  // "old" operand is irrelevant: passing 0 with bound_ctrl lets hipcc emit the DPP move without a pre-copy
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 template <int CTRL>
 __device__ __forceinline__ float dpp_move(float x) {
   int v = __float_as_int(x);
-  v = __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+  v = __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
   return __int_as_float(v);
 }
 

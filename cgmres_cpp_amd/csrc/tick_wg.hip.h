@@ -471,10 +471,13 @@ struct WgCtx {
         T* Hk = Hi + k1 * k;
         // modified Gram-Schmidt, gmres.hpp:52-58, in order; v_k itself is still in registers
         auto mgs_round = [&](const T* vi, int i) {
-          T part = 0;
+          T pa = 0, pb = 0;  // two partial sums: the fp64 FMA chain is latency-bound (8 cycles/op dependent)
 #pragma unroll
-          for (int m = 0; m < MAXM; ++m) part += vi[m] * w[m];
-          const T hik = row16_sum(part);
+          for (int m = 0; m < MAXM; m += 2) {
+            pa += vi[m] * w[m];
+            if (m + 1 < MAXM) pb += vi[m + 1] * w[m + 1];
+          }
+          const T hik = row16_sum(pa + pb);
 #pragma unroll
           for (int m = 0; m < MAXM; ++m) w[m] = w[m] - vi[m] * hik;
           if (r == 0) Hk[i] = hik;
@@ -502,11 +505,14 @@ struct WgCtx {
           }
         }
         mgs_round(vcur, k);
-        T nn = 0;
+        T na = 0, nb = 0;
 #pragma unroll
-        for (int m = 0; m < MAXM; ++m) nn += w[m] * w[m];
+        for (int m = 0; m < MAXM; m += 2) {
+          na += w[m] * w[m];
+          if (m + 1 < MAXM) nb += w[m + 1] * w[m + 1];
+        }
         CGM_STAMP(*this, 7);
-        const T hn = sqrt_t<T>(row16_sum(nn));  // :60
+        const T hn = sqrt_t<T>(row16_sum(na + nb));  // :60
         if (r == 0) {
           Hk[k + 1] = hn;
           S.nax[inst] = k + 1;
