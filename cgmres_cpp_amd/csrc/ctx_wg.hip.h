@@ -87,19 +87,9 @@ struct CtxWg final : cgmres_hip_ctx {
         (rc = dalloc(&P.n_ax, B)) || (rc = dalloc(&P.reason, B)) || (rc = dalloc(&x_dev, B * nx)) ||
         (rc = dalloc(&u_dev, B * nu)))
       return rc;
-#ifdef CGM_STAMPS
-    if ((rc = dalloc(&P.stamps, 64))) return rc;
-    g_stamps() = P.stamps;
-#endif
     HIP_TRY(hipStreamSynchronize(stream));
     return 0;
   }
-#ifdef CGM_STAMPS
-  static long long*& g_stamps() {
-    static long long* p = nullptr;
-    return p;
-  }
-#endif
 
   dim3 grid() const { return dim3((cfg.batch + ipw - 1) / ipw); }
   dim3 block() const { return dim3(ipw * 16); }

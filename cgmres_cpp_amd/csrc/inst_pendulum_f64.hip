@@ -6,6 +6,9 @@ cgmres_hip_ctx* make_pendulum_f64(const cgmres_hip_config& cfg, int* resolved) {
   return make_variant<PendulumDev<double>, double>(cfg, resolved);
 }
 #ifdef CGM_STAMPS
-long long* debug_stamps_ptr() { return CtxWg<PendulumDev<double>, double>::g_stamps(); }
+long long* debug_stamps_ptr() {
+  void* p = nullptr;
+  return hipGetSymbolAddress(&p, HIP_SYMBOL(g_cgm_stamps)) == hipSuccess ? static_cast<long long*>(p) : nullptr;
+}
 #endif
 }  // namespace cgm

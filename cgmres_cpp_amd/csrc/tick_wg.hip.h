@@ -51,15 +51,30 @@ struct WgParams {
   const T *hook_in0, *hook_in1;  // instance-major [B][L]
   T* hook_out;
   T hook_dtau;
-#ifdef CGM_STAMPS
-  long long* stamps;  // diagnostic build only (tools/phase_stamps.py): per-phase s_memtime totals of block 0
-#endif
 };
 
 // Diagnostic build only: accumulate shader-clock deltas per phase (thread 0 of block 0).  Compiles to nothing
 // in the product build.
 #ifdef CGM_STAMPS
-#define CGM_STAMP(ctx, id) (ctx).stamp(id)
+// Diagnostic build only (tools/phase_stamps.py): per-phase shader-clock totals of block 0 in a device-global buffer
+// (kept out of WgParams on purpose: any use of the kernel-argument struct through a pointer made hipcc spill the whole
+// struct to scratch and distorted the very thing being measured).
+__device__ long long g_cgm_stamps[64];
+__device__ __forceinline__ void cgm_stamp(int id) {
+  long long& t_last = g_cgm_stamps[63];
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const long long now = (long long)__builtin_amdgcn_s_memtime();
+    if (id >= 0) {
+      __hip_atomic_fetch_add(&g_cgm_stamps[id], now - t_last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(&g_cgm_stamps[32 + id], 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      g_cgm_stamps[30] = (long long)__builtin_amdgcn_s_memrealtime();
+      g_cgm_stamps[31] = now;
+    }
+    t_last = now;
+  }
+}
+#define CGM_STAMP(ctx, id) cgm_stamp(id)
 #else
 #define CGM_STAMP(ctx, id) ((void)0)
 #endif
@@ -80,7 +95,7 @@ struct WgLds {
   static __host__ __device__ size_t bytes(int dv, int kmax, int Lp, int Pp, int Hp) {
     return count_T(dv, kmax, Lp, Pp, Hp) * sizeof(T) + 4 * IPW * sizeof(int) + 16;
   }
-  __device__ WgLds(unsigned char* base, const WgParams<T>& P) {
+  __device__ __forceinline__ WgLds(unsigned char* base, const WgParams<T>& P) {
     T* q = reinterpret_cast<T*>(base);
     const int k1 = P.kmax + 1;
     U = q, q += IPW * P.Lp;
@@ -112,31 +127,14 @@ struct WgCtx {
   int bi;               // global instance of the sweep lane
   typename M::Math mc;  // per-thread math context (pinned sin/cos constants); A/B: keeping it live for the whole
                         // kernel is 13 us/tick FASTER than re-creating it inside every sweep
-#ifdef CGM_STAMPS
-  long long t_last;
-  __device__ __forceinline__ void stamp(int id) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-      const long long now = clock64();
-      atomicAdd(reinterpret_cast<unsigned long long*>(&P.stamps[id]), (unsigned long long)(now - t_last));  // no-return
-      atomicAdd(reinterpret_cast<unsigned long long*>(&P.stamps[32 + id]), 1ull);
-      t_last = now;
-    }
-  }
-#endif
-  __device__ WgCtx(const WgParams<T>& P_, unsigned char* smem)
+  __device__ __forceinline__ WgCtx(const WgParams<T>& P_, unsigned char* smem)
       : P(P_), S(smem, P_), tid(threadIdx.x), inst(threadIdx.x >> 4), r(threadIdx.x & 15) {
     b = blockIdx.x * IPW + inst;
     valid = b < P.B;
     bi = blockIdx.x * IPW + tid;
     sweep_lane = tid < IPW && bi < P.B;
     mc.init();
-#ifdef CGM_STAMPS
-    t_last = clock64();
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-      P.stamps[30] = wall_clock64();
-      P.stamps[31] = t_last;
-    }
-#endif
+    CGM_STAMP(*this, -1);
   }
   __device__ __forceinline__ int elem(int m) const { return r + 16 * m; }
 
@@ -693,8 +691,8 @@ __global__ __launch_bounds__(IPW * 16) __attribute__((amdgpu_waves_per_eu(1, 1))
   CGM_STAMP(C, 13);
 #ifdef CGM_STAMPS
   if (threadIdx.x == 0 && blockIdx.x == 0) {
-    P.stamps[28] += wall_clock64() - P.stamps[30];
-    P.stamps[29] += clock64() - P.stamps[31];
+    g_cgm_stamps[28] += (long long)__builtin_amdgcn_s_memrealtime() - g_cgm_stamps[30];
+    g_cgm_stamps[29] += (long long)__builtin_amdgcn_s_memtime() - g_cgm_stamps[31];
   }
 #endif
 }

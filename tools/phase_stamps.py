@@ -10,7 +10,7 @@ from cgmres_cpp_amd import build as b
 diag = os.path.join(ROOT, "_diag")  # git-ignored, but travels with gpurun (gpurun_out/ does not)
 os.makedirs(diag, exist_ok=True)
 lib = os.path.join(diag, "libcgmres_hip_stamps.so")
-if "--build" in sys.argv or not os.path.exists(lib):
+if "--build" in sys.argv or "--build-only" in sys.argv or not os.path.exists(lib):
     srcs, _ = b.sources()
     from concurrent.futures import ThreadPoolExecutor
     def cc(s):
