@@ -42,6 +42,7 @@ struct WgParams {
   // instance-major HBM state
   T *U, *dUdt, *Fh, *V, *xdxh, *ptau;  // [B][Lg], [B][Lg], [B][Lg], [B][kmax+1][Lg], [B][NX], [B][NP*(dv+1)]
   T* kry;                              // [B][KS]: H (k1*k1 col-major) | rho (k1) | g (3*kmax)
+  T* scr;                              // [workgroups][2][dv*NSTG*IPW]: parked stage tables of the preamble sweeps
   int *n_ax, *reason;
   const T* x_in;  // [B][NX]
   T* u_out;       // [B][NU]
@@ -90,7 +91,7 @@ struct WgLds {
   static __host__ __device__ size_t count_T(int dv, int kmax, int Lp, int Pp, int Hp) {
     const int k1 = kmax + 1;
     return size_t(3) * IPW * Lp + size_t(dv) * NSTG * IPW + size_t(IPW) * Pp + size_t(IPW) * Hp + size_t(IPW) * k1 +
-           size_t(IPW) * 3 * kmax + size_t(3) * M::NX * IPW;
+           size_t(IPW) * 3 * kmax + size_t(5) * M::NX * IPW;
   }
   static __host__ __device__ size_t bytes(int dv, int kmax, int Lp, int Pp, int Hp) {
     return count_T(dv, kmax, Lp, Pp, Hp) * sizeof(T) + 4 * IPW * sizeof(int) + 16;
@@ -108,7 +109,7 @@ struct WgLds {
     g = q, q += IPW * 3 * P.kmax;
     xs = q, q += M::NX * IPW;
     xh = q, q += M::NX * IPW;
-    xT = q, q += M::NX * IPW;
+    xT = q, q += 3 * M::NX * IPW;  // three terminal states: the preamble sweeps run concurrently
     int* z = reinterpret_cast<int*>(q);
     flag = z, reason = z + IPW, nax = z + 2 * IPW, ksolve = z + 3 * IPW;
   }
@@ -231,24 +232,26 @@ struct WgCtx {
   //   MODE F_PLAIN: out = F        F_RHS: out = (F*(1-zeta h) - Fh)/h  (:91-96)        F_AX: out = (F - Fh)/h  (:173-174)
   //   PERT: u = U + h*W.  `out` may be W itself: every (stage, instance) entry of W is read for the last time in
   //   phase 2 by the thread that then overwrites it.
-  // COLLECTIVE: every thread of the block must call it (two workgroup barriers inside); the caller adds the
-  // barrier that publishes `out`.  x0c = initial state, component-major LDS [c*IPW + i].
-  template <bool PERT, int MODE>
-  __device__ __forceinline__ void f_eval(const T* x0c, T dtau, T* out, bool only_active) {
-    constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC, NBW = M::NBW, NUL = M::NUL;
-    const int dv = P.dv;
-    const bool go = sweep_lane && (!only_active || S.flag[tid]);
-    // phase 1: state sweep, cgmres.hpp:132-140; leaves x(dv) in S.xT
+  // Three phases (see the header comment).  A stage table is dv*NSTG*IPW scalars indexed [(stage*NSTG + slot)*IPW + i];
+  // phase 1 writes x(s), trig(s) to `tab` — the LDS table S.R or, for the concurrent preamble sweeps, a per-workgroup
+  // table in HBM — phase 2 reads `tab` and leaves the costate coefficients in S.R, phase 3 consumes S.R.
+
+  // phase 1: state sweep, cgmres.hpp:132-140, on the lanes [lane0, lane0 + 64) of one wave; x(dv) -> xT[c*IPW + i]
+  template <bool PERT>
+  __device__ __forceinline__ void sweep_state(int lane0, const T* x0c, T dtau, T* tab, T* xT, bool only_active) {
+    constexpr int NX = M::NX, NU = M::NU, NC = M::NC;
+    const int dv = P.dv, lt = tid - lane0;
+    if (lt < 0 || lt >= 64) return;
     if constexpr (M::HAS_QUAD_SWEEP) {
-      // four lanes (one DPP quad) per instance — see PendulumDev::quad_stage
-      const int qi = tid >> 2, rho = tid & 3;
-      const bool goq = tid < 4 * IPW && blockIdx.x * IPW + qi < P.B && (!only_active || S.flag[qi]);
+      // four lanes (one DPP quad) per instance — see PendulumDev::quad_trig / quad_advance
+      const int qi = lt >> 2, rho = lt & 3;
+      const bool goq = lt < 4 * IPW && blockIdx.x * IPW + qi < P.B && (!only_active || S.flag[qi]);
       if (goq) {
         typename M::QuadLane Q;
         Q.init(rho, mc);
         const T* __restrict__ U = S.U + qi * P.Lp;
         const T* W = S.W + qi * P.Lp;
-        T* __restrict__ R = S.R + qi;
+        T* __restrict__ R = tab + qi;
         T x[NX];
         // one branch-free block per stage: store x(s) and its trig value, advance to x(s+1), start the trig of
         // stage s+1 — the scheduler overlaps the trig chain of s+1 with the dxdt[3] chain of s
@@ -274,111 +277,133 @@ struct WgCtx {
         if (__builtin_expect(__any(sweep(std::false_type{})), 0)) sweep(std::true_type{});
         if (rho == 0) {
 #pragma unroll
-          for (int c = 0; c < NX; ++c) S.xT[c * IPW + qi] = x[c];
+          for (int c = 0; c < NX; ++c) xT[c * IPW + qi] = x[c];
         }
       }
-    } else if (go) {
-      const int i = tid;
-      const T* __restrict__ U = S.U + i * P.Lp;
-      const T* W = S.W + i * P.Lp;
-      T* __restrict__ R = S.R + i;
-      T xs[NX];
+    } else {
+      const int i = lt;
+      if (i < IPW && blockIdx.x * IPW + i < P.B && (!only_active || S.flag[i])) {
+        const T* __restrict__ U = S.U + i * P.Lp;
+        const T* W = S.W + i * P.Lp;
+        T* __restrict__ R = tab + i;
+        T xs[NX];
 #pragma unroll
-      for (int c = 0; c < NX; ++c) xs[c] = x0c[c * IPW + i];
-      for (int s = 0; s < dv; ++s) {
-        T u[M::NU_DYN], f[NX], tr[NC > 0 ? NC : 1];
+        for (int c = 0; c < NX; ++c) xs[c] = x0c[c * IPW + i];
+        for (int s = 0; s < dv; ++s) {
+          T u[M::NU_DYN], f[NX], tr[NC > 0 ? NC : 1];
 #pragma unroll
-        for (int j = 0; j < M::NU_DYN; ++j) {
-          T uj = U[s * NU + j];
-          if (PERT) uj = W[s * NU + j] * P.h + uj;
-          u[j] = uj;
+          for (int j = 0; j < M::NU_DYN; ++j) {
+            T uj = U[s * NU + j];
+            if (PERT) uj = W[s * NU + j] * P.h + uj;
+            u[j] = uj;
+          }
+#pragma unroll
+          for (int c = 0; c < NX; ++c) R[(s * NSTG + c) * IPW] = xs[c];
+          M::dxdt(f, xs, u, tr, mc);
+#pragma unroll
+          for (int c = 0; c < NC; ++c) R[(s * NSTG + NX + c) * IPW] = tr[c];
+#pragma unroll
+          for (int c = 0; c < NX; ++c) xs[c] = f[c] * dtau + xs[c];
         }
 #pragma unroll
-        for (int c = 0; c < NX; ++c) R[(s * NSTG + c) * IPW] = xs[c];
-        M::dxdt(f, xs, u, tr, mc);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) R[(s * NSTG + NX + c) * IPW] = tr[c];
-#pragma unroll
-        for (int c = 0; c < NX; ++c) xs[c] = f[c] * dtau + xs[c];
+        for (int c = 0; c < NX; ++c) xT[c * IPW + i] = xs[c];
       }
-#pragma unroll
-      for (int c = 0; c < NX; ++c) S.xT[c * IPW + i] = xs[c];
     }
+  }
+
+  // phase 2: costate-free part of every backward stage, all threads, items (s, i) with i fastest.
+  // Reads x/trig from `tab`, writes the coefficients to S.R and the costate-free part of the result to `out`.
+  template <bool PERT, int MODE>
+  __device__ __forceinline__ void sweep_coeffs(T dtau, const T* tab, T* out, bool only_active) {
+    constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC, NBW = M::NBW;
+    const int dv = P.dv;
+    const T sc_phi = MODE == F_RHS ? P.one_m_zh : T(1.0);
+    for (int q = tid; q < dv * IPW; q += IPW * 16) {
+      const int i = q & (IPW - 1), s = q / IPW;
+      if (blockIdx.x * IPW + i >= P.B) continue;
+      if (only_active && !S.flag[i]) continue;
+      T x[NX], tr[NC > 0 ? NC : 1], u[NU], p[NP > 0 ? NP : 1], bw[NBW], phi[NU];
+      const T* Rs = tab + (s * NSTG) * IPW + i;
+      T* Rd = S.R + (s * NSTG) * IPW + i;
+#pragma unroll
+      for (int c = 0; c < NX; ++c) x[c] = Rs[c * IPW];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) tr[c] = Rs[(NX + c) * IPW];
+#pragma unroll
+      for (int j = 0; j < NU; ++j) {
+        T uj = S.U[i * P.Lp + s * NU + j];
+        if (PERT) uj = S.W[i * P.Lp + s * NU + j] * P.h + uj;
+        u[j] = uj;
+      }
+#pragma unroll
+      for (int j = 0; j < NP; ++j) p[j] = S.p[i * P.Pp + s * NP + j];
+      M::stage_coeffs(bw, phi, x, u, p, tr, dtau);
+#pragma unroll
+      for (int c = 0; c < NBW; ++c) Rd[c * IPW] = bw[c];
+#pragma unroll
+      for (int j = 0; j < NU; ++j) {
+        T rj = phi[j];
+        if (MODE != F_PLAIN) rj = (rj * sc_phi - S.Fh[i * P.Lp + s * NU + j]) * P.inv_h;
+        out[i * P.Lp + s * NU + j] = rj;
+      }
+    }
+  }
+
+  // phase 3: costate sweep (cgmres.hpp:145-153) + the costate part of dH/du (:156-161), lanes 0..IPW-1 of wave 0
+  template <int MODE>
+  __device__ __forceinline__ void sweep_costate(T dtau, const T* xT, T* out, bool only_active) {
+    constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NBW = M::NBW, NUL = M::NUL;
+    const int dv = P.dv;
+    if (!(sweep_lane && (!only_active || S.flag[tid]))) return;
+    const int i = tid;
+    const T sc = MODE == F_PLAIN ? T(1.0) : (MODE == F_RHS ? P.one_m_zh * P.inv_h : P.inv_h);
+    T l[NX], xs[NX], p[NP > 0 ? NP : 1];
+#pragma unroll
+    for (int c = 0; c < NX; ++c) xs[c] = xT[c * IPW + i];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) p[j] = S.p[i * P.Pp + dv * NP + j];
+    M::dPhidx(l, xs, p);
+    T* o = out + i * P.Lp;
+    const T* R = S.R + i;
+    // two register sets, unrolled by two: the LDS operands of stage s-1 are in flight while stage s computes
+    struct Ops {
+      T bw[NBW], o[NUL];
+    };
+    auto fetch = [&](Ops& a, int s) {
+#pragma unroll
+      for (int c = 0; c < NBW; ++c) a.bw[c] = R[(s * NSTG + c) * IPW];
+#pragma unroll
+      for (int j = 0; j < NUL; ++j) a.o[j] = o[s * NU + j];
+    };
+    auto stage = [&](const Ops& a, int s) {
+      T dF[NUL];
+      M::costate_step(l, dF, a.bw, dtau);
+#pragma unroll
+      for (int j = 0; j < NUL; ++j) o[s * NU + j] = a.o[j] + dF[j] * sc;
+    };
+    Ops A, B;
+    int s = dv - 1;
+    fetch(A, s);
+    for (; s >= 1; s -= 2) {
+      fetch(B, s - 1);
+      stage(A, s);
+      if (s >= 2) fetch(A, s - 2);
+      stage(B, s - 1);
+    }
+    if (s == 0) stage(A, 0);
+  }
+
+  // One complete sweep on the LDS table.  COLLECTIVE: every thread of the block must call it (two workgroup barriers
+  // inside); the caller adds the barrier that publishes `out`.  x0c = initial state, component-major LDS [c*IPW + i].
+  template <bool PERT, int MODE>
+  __device__ __forceinline__ void f_eval(const T* x0c, T dtau, T* out, bool only_active) {
+    sweep_state<PERT>(0, x0c, dtau, S.R, S.xT, only_active);
     __syncthreads();
     CGM_STAMP(*this, 4);
-    // phase 2: costate-free part of every backward stage, all threads, items (s, i) with i fastest
-    {
-      const T sc_phi = MODE == F_RHS ? P.one_m_zh : T(1.0);
-      for (int q = tid; q < dv * IPW; q += IPW * 16) {
-        const int i = q & (IPW - 1), s = q / IPW;
-        if (blockIdx.x * IPW + i >= P.B) continue;
-        if (only_active && !S.flag[i]) continue;
-        T x[NX], tr[NC > 0 ? NC : 1], u[NU], p[NP > 0 ? NP : 1], bw[NBW], phi[NU];
-        T* R = S.R + (s * NSTG) * IPW + i;
-#pragma unroll
-        for (int c = 0; c < NX; ++c) x[c] = R[c * IPW];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) tr[c] = R[(NX + c) * IPW];
-#pragma unroll
-        for (int j = 0; j < NU; ++j) {
-          T uj = S.U[i * P.Lp + s * NU + j];
-          if (PERT) uj = S.W[i * P.Lp + s * NU + j] * P.h + uj;
-          u[j] = uj;
-        }
-#pragma unroll
-        for (int j = 0; j < NP; ++j) p[j] = S.p[i * P.Pp + s * NP + j];
-        M::stage_coeffs(bw, phi, x, u, p, tr, dtau);
-#pragma unroll
-        for (int c = 0; c < NBW; ++c) R[c * IPW] = bw[c];
-#pragma unroll
-        for (int j = 0; j < NU; ++j) {
-          T rj = phi[j];
-          if (MODE != F_PLAIN) rj = (rj * sc_phi - S.Fh[i * P.Lp + s * NU + j]) * P.inv_h;
-          out[i * P.Lp + s * NU + j] = rj;
-        }
-      }
-    }
+    sweep_coeffs<PERT, MODE>(dtau, S.R, out, only_active);
     __syncthreads();
     CGM_STAMP(*this, 5);
-    // phase 3: costate sweep (cgmres.hpp:145-153) + the costate part of dH/du (:156-161)
-    if (go) {
-      const int i = tid;
-      const T sc = MODE == F_PLAIN ? T(1.0) : (MODE == F_RHS ? P.one_m_zh * P.inv_h : P.inv_h);
-      T l[NX], xs[NX], p[NP > 0 ? NP : 1];
-#pragma unroll
-      for (int c = 0; c < NX; ++c) xs[c] = S.xT[c * IPW + i];
-#pragma unroll
-      for (int j = 0; j < NP; ++j) p[j] = S.p[i * P.Pp + dv * NP + j];
-      M::dPhidx(l, xs, p);
-      T* o = out + i * P.Lp;
-      const T* R = S.R + i;
-      // two register sets, unrolled by two: the LDS operands of stage s-1 are in flight while stage s computes
-      struct Ops {
-        T bw[NBW], o[NUL];
-      };
-      auto fetch = [&](Ops& a, int s) {
-#pragma unroll
-        for (int c = 0; c < NBW; ++c) a.bw[c] = R[(s * NSTG + c) * IPW];
-#pragma unroll
-        for (int j = 0; j < NUL; ++j) a.o[j] = o[s * NU + j];
-      };
-      auto stage = [&](const Ops& a, int s) {
-        T dF[NUL];
-        M::costate_step(l, dF, a.bw, dtau);
-#pragma unroll
-        for (int j = 0; j < NUL; ++j) o[s * NU + j] = a.o[j] + dF[j] * sc;
-      };
-      Ops A, B;
-      int s = dv - 1;
-      fetch(A, s);
-      for (; s >= 1; s -= 2) {
-        fetch(B, s - 1);
-        stage(A, s);
-        if (s >= 2) fetch(A, s - 2);
-        stage(B, s - 1);
-      }
-      if (s == 0) stage(A, 0);
-    }
+    sweep_costate<MODE>(dtau, S.xT, out, only_active);
   }
 
   // cgmres.hpp:83-85 on the sweep lanes: x_dxh = x + h*f(x, U0)
@@ -395,13 +420,61 @@ struct WgCtx {
 #pragma unroll
     for (int c = 0; c < NX; ++c) S.xh[c * IPW + i] = f[c] * P.h + x[c];
   }
-  // cgmres.hpp:83-96: x_dxh, Fh = F(U, x_dxh, t+h), W = b.  Collective; ends with W published.
-  __device__ __forceinline__ void preamble() {
-    make_xh();  // read back by the same lanes only
-    f_eval<false, F_PLAIN>(S.xh, P.dtau_h, S.Fh, false);
+  // The three sweeps control() needs before the Arnoldi loop are independent of each other
+  //     #1 Fh  = F(U, x_dxh, t+h)              cgmres.hpp:88
+  //     #2 b   = (F(U, x, t)(1-zeta h) - Fh)/h   :91-96
+  //     #3 Ax0 = (F(U + h dUdt, x_dxh, t+h) - Fh)/h   :99 -> gmres.hpp:33 (only when WITH_AX0; W must hold dUdt)
+  // so their state sweeps — the long serial phase — run CONCURRENTLY on waves 0, 1, 2; #1 uses the LDS stage table,
+  // #2/#3 park theirs in this workgroup's HBM scratch (written once, read once by the parallel coefficient phase).
+  // Results: Fh in S.Fh; b and Ax0 delivered in registers (row layout) because both pass through S.W.
+  // COLLECTIVE; needs at least 3 waves (falls back to sequential sweeps otherwise).
+  template <bool WITH_AX0>
+  __device__ __forceinline__ void preamble(T* bb, T* ax0) {
+    make_xh();
     __syncthreads();
-    f_eval<false, F_RHS>(S.xs, P.dtau_0, S.W, false);
-    __syncthreads();
+    if constexpr (IPW * 16 >= 192) {
+      const size_t tab_n = size_t(P.dv) * NSTG * IPW;
+      T* tab0 = P.scr + size_t(blockIdx.x) * 2 * tab_n;
+      T* tab1 = tab0 + tab_n;
+      T* xT0 = S.xT, *xT1 = S.xT + M::NX * IPW, *xT2 = S.xT + 2 * M::NX * IPW;
+      sweep_state<false>(0, S.xh, P.dtau_h, S.R, xT0, false);
+      sweep_state<false>(64, S.xs, P.dtau_0, tab0, xT1, false);
+      if (WITH_AX0) sweep_state<true>(128, S.xh, P.dtau_h, tab1, xT2, false);
+      __threadfence_block();
+      __syncthreads();  // drains vmcnt: the HBM tables are complete and visible to the other waves of this CU
+      CGM_STAMP(*this, 4);
+      sweep_coeffs<false, F_PLAIN>(P.dtau_h, S.R, S.Fh, false);
+      __syncthreads();
+      sweep_costate<F_PLAIN>(P.dtau_h, xT0, S.Fh, false);
+      __syncthreads();
+      if (WITH_AX0) {
+        sweep_coeffs<true, F_AX>(P.dtau_h, tab1, S.W, false);
+        __syncthreads();
+        sweep_costate<F_AX>(P.dtau_h, xT2, S.W, false);
+        __syncthreads();
+        lds_to_reg(ax0, S.W);
+        __syncthreads();
+      }
+      sweep_coeffs<false, F_RHS>(P.dtau_0, tab0, S.W, false);
+      __syncthreads();
+      sweep_costate<F_RHS>(P.dtau_0, xT1, S.W, false);
+      __syncthreads();
+      lds_to_reg(bb, S.W);
+      __syncthreads();
+    } else {
+      f_eval<false, F_PLAIN>(S.xh, P.dtau_h, S.Fh, false);
+      __syncthreads();
+      if (WITH_AX0) {
+        f_eval<true, F_AX>(S.xh, P.dtau_h, S.W, false);
+        __syncthreads();
+        lds_to_reg(ax0, S.W);
+        __syncthreads();
+      }
+      f_eval<false, F_RHS>(S.xs, P.dtau_0, S.W, false);
+      __syncthreads();
+      lds_to_reg(bb, S.W);
+      __syncthreads();
+    }
   }
   // Ax_func in place on W (cgmres.hpp:164-175).  Collective; ends with W published.
   __device__ __forceinline__ void ax(bool only_active) {
@@ -411,9 +484,9 @@ struct WgCtx {
     CGM_STAMP(*this, 6);
   }
 
-  // Gmres::gmres (gmres.hpp:28-112).  In: x (registers `xv`), b (registers `bb`), W = A*x0 already in LDS.
+  // Gmres::gmres (gmres.hpp:28-112).  In: x (registers `xv`), b (`bb`) and A*x0 (`ax0`), all in the row layout.
   // Out: xv updated.  All threads of the block must call this (it contains workgroup barriers).
-  __device__ __forceinline__ void gmres(T* xv, const T* bb) {
+  __device__ __forceinline__ void gmres(T* xv, const T* bb, const T* ax0) {
     const int kmax = P.kmax, k1 = kmax + 1;
     T* Hi = S.H + inst * P.Hp;
     T* rhoi = S.rho + inst * k1;
@@ -430,8 +503,6 @@ struct WgCtx {
     bool active = valid;
     // r0 = b - A x0 ; rho = ||r0||      gmres.hpp:33-37
     {
-      T ax0[MAXM];
-      lds_to_reg(ax0, S.W);
       T ss = 0;
 #pragma unroll
       for (int m = 0; m < MAXM; ++m) {
@@ -653,14 +724,11 @@ __global__ __launch_bounds__(IPW * 16) __attribute__((amdgpu_waves_per_eu(1, 1))
   for (int q = C.r; q < P.Hp; q += 16) C.S.H[C.inst * P.Hp + q] = T(0);
   __syncthreads();
   CGM_STAMP(C, 0);
-  C.preamble();  // Fh, W = b
-  CGM_STAMP(C, 1);
-  C.lds_to_reg(bb, C.S.W);
-  __syncthreads();
   C.reg_to_lds(C.S.W, du);  // direction of the first mat-vec: x0 = dUdt (warm start, cgmres.hpp:99)
-  __syncthreads();
-  C.ax(false);  // W <- A dUdt
-  C.gmres(du, bb);
+  T ax0[MAXM];
+  C.template preamble<true>(bb, ax0);  // Fh in LDS; b and A*dUdt in registers
+  CGM_STAMP(C, 1);
+  C.gmres(du, bb, ax0);
   CGM_STAMP(C, 12);
   // U += dUdt*dt, u = U[0:dim_u]  (cgmres.hpp:102-109)
   T un[MAXM];
@@ -734,8 +802,7 @@ __global__ __launch_bounds__(IPW * 16) __attribute__((amdgpu_waves_per_eu(1, 1))
   if (P.mode == WG_HOOK_PREPARE) {  // cgmres.hpp:83-96
     C.load_common(P.U);
     __syncthreads();
-    C.preamble();
-    C.lds_to_reg(a, C.S.W);
+    C.template preamble<false>(a, c2);
     if (P.hook_out) store_im(P.hook_out, a);
     C.lds_to_reg(a, C.S.Fh);
     C.reg_to_row(P.Fh, P.Lg, a);
@@ -757,7 +824,9 @@ __global__ __launch_bounds__(IPW * 16) __attribute__((amdgpu_waves_per_eu(1, 1))
     return;
   }
   load_im(c2, P.hook_in1);
-  C.gmres(a, c2);
+  T ax0h[MAXM];
+  C.lds_to_reg(ax0h, C.S.W);
+  C.gmres(a, c2, ax0h);
   store_im(P.hook_out, a);
   C.store_status();
 }
