@@ -62,7 +62,7 @@ struct WgParams {
 // struct to scratch and distorted the very thing being measured).
 __device__ long long g_cgm_stamps[64];
 __device__ __forceinline__ void cgm_stamp(int id) {
-  long long& t_last = g_cgm_stamps[63];
+  __shared__ long long t_last;  // LDS, not global: a global read would make every stamp drain vmcnt(0)
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const long long now = (long long)__builtin_amdgcn_s_memtime();
     if (id >= 0) {
@@ -526,7 +526,9 @@ struct WgCtx {
     }
     int k = 0;
     for (; k < kmax; ++k) {  // gmres.hpp:46
+      CGM_STAMP(*this, 14);
       if (!__syncthreads_or(active ? 1 : 0)) break;  // also publishes W / flag to the sweep lanes
+      CGM_STAMP(*this, 15);
       // The first basis vectors this iteration needs are requested from HBM/L2 NOW: they arrive while wave 0 sweeps.
       T vbuf[NBUF][MAXM];
       if (preload && active) {

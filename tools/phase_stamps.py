@@ -37,7 +37,7 @@ L.cgmres_hip_debug_stamps(out)
 N = 100
 c.closed_loop_device(xd, ud, N); c.synchronize()
 L.cgmres_hip_debug_stamps(out)
-names = {0: "prologue loads", 1: "preamble (2 sweeps)", 3: "pre-sweep (shuffles, barrier_or)", 4: "sweep phase 1 (state)",
+names = {14: "loop top: before barrier_or", 15: "barrier_or (drains V row store)", 0: "prologue loads", 1: "preamble (2 sweeps)", 3: "ring preload issue", 4: "sweep phase 1 (state)",
          5: "sweep phase 2 (coeffs)", 6: "sweep phase 3 (costate)", 7: "MGS rounds", 8: "norm+normalise+store",
          9: "Hessenberg scalar", 10: "loop exit barrier", 11: "back-subst", 12: "x update (V*y)", 13: "epilogue"}
 tot = out[29]; wall = out[28]
