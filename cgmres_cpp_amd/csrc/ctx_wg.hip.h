@@ -75,14 +75,14 @@ struct CtxWg final : cgmres_hip_ctx {
     const int k1 = cfg.k_max + 1;
     ks_all = k1 * k1 + k1 + 3 * cfg.k_max;
     P.B = cfg.batch, P.dv = cfg.dv, P.kmax = cfg.k_max, P.L = L;
-    P.Lp = L | 1, P.Lg = (L + 15) / 16 * 16, P.Pp = (np * (cfg.dv + 1)) | 1, P.Hp = (k1 * k1) | 1;
+    P.Lp = L | 1, P.Lg = (L + 15) / 16 * 16, P.Lv = 16 * maxm, P.Pp = (np * (cfg.dv + 1)) | 1, P.Hp = (k1 * k1) | 1;
     P.h = T(cfg.h), P.dt = T(cfg.dt), P.tol = T(cfg.tol);
     P.inv_h = T(1.0) / P.h;
     P.one_m_zh = (1 - T(cfg.zeta) * P.h);
     const size_t B = cfg.batch, Lg = P.Lg;
     int rc = 0;
     if ((rc = dalloc(&P.U, B * Lg)) || (rc = dalloc(&P.dUdt, B * Lg)) || (rc = dalloc(&P.Fh, B * Lg)) ||
-        (rc = dalloc(&P.V, B * k1 * Lg)) || (rc = dalloc(&P.xdxh, B * nx)) ||
+        (rc = dalloc(&P.V, B * k1 * size_t(P.Lv))) || (rc = dalloc(&P.xdxh, B * nx)) ||
         (rc = dalloc(&P.ptau, B * size_t(np) * (cfg.dv + 1))) || (rc = dalloc(&P.kry, B * ks_all)) ||
         (rc = dalloc(&P.scr, size_t((cfg.batch + ipw - 1) / ipw) * 2 * cfg.dv * WgLds<M, T, 16>::NSTG * ipw)) ||
         (rc = dalloc(&P.n_ax, B)) || (rc = dalloc(&P.reason, B)) || (rc = dalloc(&x_dev, B * nx)) ||
@@ -211,7 +211,7 @@ struct CtxWg final : cgmres_hip_ctx {
   int get_krylov(void* V, void* H, void* rho, void* g) override {
     HIP_TRY(hipSetDevice(cfg.device));
     const int k1 = cfg.k_max + 1;
-    if (int rc = rows_d2h(V, P.V, P.Lg, L, size_t(cfg.batch) * k1)) return rc;
+    if (int rc = rows_d2h(V, P.V, P.Lv, L, size_t(cfg.batch) * k1)) return rc;
     if (H)
       if (int rc = rows_d2h(H, P.kry, ks_all, k1 * k1, cfg.batch)) return rc;
     if (rho)

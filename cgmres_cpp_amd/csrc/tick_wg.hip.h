@@ -37,10 +37,11 @@ enum WgMode { WG_TICK = 0, WG_HOOK_F = 1, WG_HOOK_PREPARE = 2, WG_HOOK_AX = 3, W
 
 template <class T>
 struct WgParams {
-  int B, dv, kmax, L, Lp, Lg, Pp, Hp;  // Lp/Pp/Hp: odd LDS row pitches; Lg: global row pitch (multiple of 16)
+  int B, dv, kmax, L, Lp, Lg, Lv, Pp, Hp;  // Lp/Pp/Hp: odd LDS row pitches; Lg: global row pitch (multiple of 16);
+                                        // Lv = 16*MAXM: pitch of the Krylov rows (pads kept zero, no guards)
   T h, dt, tol, inv_h, one_m_zh, dtau_h, dtau_0;
   // instance-major HBM state
-  T *U, *dUdt, *Fh, *V, *xdxh, *ptau;  // [B][Lg], [B][Lg], [B][Lg], [B][kmax+1][Lg], [B][NX], [B][NP*(dv+1)]
+  T *U, *dUdt, *Fh, *V, *xdxh, *ptau;  // [B][Lg], [B][Lg], [B][Lg], [B][kmax+1][Lv], [B][NX], [B][NP*(dv+1)]
   T* kry;                              // [B][KS]: H (k1*k1 col-major) | rho (k1) | g (3*kmax)
   T* scr;                              // [workgroups][2][dv*NSTG*IPW]: parked stage tables of the preamble sweeps
   int *n_ax, *reason;
@@ -178,21 +179,19 @@ struct WgCtx {
     }
   }
   __device__ __forceinline__ T* vrow(int j) const {  // Krylov vector j of this row's instance
-    return P.V + (size_t(b) * (P.kmax + 1) + j) * P.Lg;
+    return P.V + (size_t(b) * (P.kmax + 1) + j) * P.Lv;
   }
+  // Krylov rows have pitch 16*MAXM and zero pads (every vector written here has zero pads: lds_to_reg clears
+  // them and all later operations are linear), so neither direction needs a guard.  That matters for more than the
+  // compare: a guarded load is an exec-masked branch, and the compiler cannot count outstanding loads across
+  // branches — every wait in the Gram-Schmidt rounds became vmcnt(0) and serialised the register ring.
   __device__ __forceinline__ void load_vec(T* reg, const T* row) const {
 #pragma unroll
-    for (int m = 0; m < MAXM; ++m) {
-      const int e = elem(m);
-      reg[m] = (e < P.L) ? row[e] : T(0);
-    }
+    for (int m = 0; m < MAXM; ++m) reg[m] = row[elem(m)];
   }
   __device__ __forceinline__ void store_vec(T* row, const T* reg) const {
 #pragma unroll
-    for (int m = 0; m < MAXM; ++m) {
-      const int e = elem(m);
-      if (e < P.L) row[e] = reg[m];
-    }
+    for (int m = 0; m < MAXM; ++m) row[elem(m)] = reg[m];
   }
 
   // Common prologue: U, ptau -> LDS; x -> LDS (component-major); flags cleared.  All global loads of the row are
@@ -494,12 +493,19 @@ struct WgCtx {
     T vcur[MAXM], w[MAXM];
     // Ring of NBUF register buffers for the older basis vectors: NBUF rows are requested before the sweep starts, and
     // every buffer is refilled with row i+NBUF as soon as round i has consumed it, so each load has NBUF-1 rounds
-    // (~1000 cycles) to arrive.  Static buffer indices: NGEN generations x NBUF buffers, fully unrolled.
+    // (~1000 cycles) to arrive.  Static buffer indices: one fully unrolled instance per iteration count (<= KRING).
 #ifndef CGM_AB_NBUF
 #define CGM_AB_NBUF 3
 #endif
-    constexpr int NBUF = MAXM <= 10 ? CGM_AB_NBUF : 2, NGEN = 12 / NBUF;
-    const bool preload = kmax <= NBUF * NGEN;  // workgroup-uniform; longer bases use the plain streaming loop
+#define CGM_KCASE(f, n) \
+  case n:               \
+    f(std::integral_constant<int, n>{}); \
+    break;
+#define CGM_KCASES(f) \
+  CGM_KCASE(f, 1) CGM_KCASE(f, 2) CGM_KCASE(f, 3) CGM_KCASE(f, 4) CGM_KCASE(f, 5) CGM_KCASE(f, 6) CGM_KCASE(f, 7) \
+  CGM_KCASE(f, 8) CGM_KCASE(f, 9) CGM_KCASE(f, 10) CGM_KCASE(f, 11) CGM_KCASE(f, 12)
+    constexpr int NBUF = MAXM <= 10 ? CGM_AB_NBUF : 2, KRING = 12;
+    const bool preload = kmax <= KRING;  // workgroup-uniform; longer bases use the plain streaming loop
     bool active = valid;
     // r0 = b - A x0 ; rho = ||r0||      gmres.hpp:33-37
     {
@@ -554,16 +560,19 @@ struct WgCtx {
           if (r == 0) Hk[i] = hik;
         };
         if (preload) {
+          // One straight-line instance per k: with no branch between a load and its use the compiler counts the
+          // outstanding loads exactly (s_waitcnt vmcnt(2*MAXM) in the steady state instead of vmcnt(0)).
+          auto rounds = [&](auto kc) {
+            constexpr int K = decltype(kc)::value;
 #pragma unroll
-          for (int gen = 0; gen < NGEN; ++gen) {
-#pragma unroll
-            for (int bi = 0; bi < NBUF; ++bi) {
-              const int i = gen * NBUF + bi;
-              if (i < k) {
-                mgs_round(vbuf[bi], i);
-                if (i + NBUF < k) load_vec(vbuf[bi], vrow(i + NBUF));
-              }
+            for (int i = 0; i < K; ++i) {
+              mgs_round(vbuf[i % NBUF], i);
+              if (i + NBUF < K) load_vec(vbuf[i % NBUF], vrow(i + NBUF));
             }
+          };
+          switch (k) {
+            CGM_KCASES(rounds)
+            default: break;
           }
         } else {
           T vi[MAXM], vn[MAXM];
@@ -671,18 +680,19 @@ struct WgCtx {
 #pragma unroll
         for (int j = 0; j < NBUF; ++j)
           if (j < ks) load_vec(vbuf[j], vrow(j));
+        auto rounds = [&](auto kc) {
+          constexpr int K = decltype(kc)::value;
 #pragma unroll
-        for (int gen = 0; gen < NGEN; ++gen) {
+          for (int j = 0; j < K; ++j) {
+            const T yj = rhoi[j];
 #pragma unroll
-          for (int bi = 0; bi < NBUF; ++bi) {
-            const int j = gen * NBUF + bi;
-            if (j < ks) {
-              const T yj = rhoi[j];
-#pragma unroll
-              for (int m = 0; m < MAXM; ++m) acc[m] += vbuf[bi][m] * yj;
-              if (j + NBUF < ks) load_vec(vbuf[bi], vrow(j + NBUF));
-            }
+            for (int m = 0; m < MAXM; ++m) acc[m] += vbuf[j % NBUF][m] * yj;
+            if (j + NBUF < K) load_vec(vbuf[j % NBUF], vrow(j + NBUF));
           }
+        };
+        switch (ks) {
+          CGM_KCASES(rounds)
+          default: break;
         }
       } else {
         for (int j = 0; j < ks; ++j) {
