@@ -42,6 +42,12 @@ __device__ __forceinline__ double fma3(double a, double b, double c) {
   return d;
 }
 
+__device__ __forceinline__ double mul2(double a, double b) {  // a*b that hipcc cannot fuse into a following add
+  double d;
+  asm("v_mul_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
 // The 15 fp64 constants of the routine, held in VGPRs for the lifetime of a thread.  They are made opaque
 // to the optimiser on purpose: with the scalar register file saturated by the kernel's pointers hipcc would
 // otherwise re-materialise every constant in every stage (22 s_mov + 12 v_mov per sincos pair).
@@ -290,6 +296,64 @@ struct PendulumDev {
     x[2] = __builtin_fma(dtau, f2, x[2]);
     x[3] = __builtin_fma(dtau, f3, x[3]);
   }
+  // One whole stage, hand-scheduled: x(s), v = trig(x(s)) -> x(s+1), v = trig(x(s+1)).  Same arithmetic as
+  // quad_advance followed by quad_trig, but issued in an explicit order that alternates the long chain (the trig of
+  // stage s+1, 17 dependent levels) with the short one (dxdt[3] of stage s, which needs the trig of stage s): a
+  // wave64 fp64 op issues in 4 cycles and its result is ready after 8, so every dependent pair needs exactly one
+  // independent instruction in between.  Left to itself hipcc emits the two chains one after the other (~430
+  // cycles/stage measured; the issue bound of the ~60 instructions is ~240).  CGM_SB pins the order.
+#define CGM_SB() __builtin_amdgcn_sched_barrier(0)
+  template <bool SLOW>
+  static __device__ __forceinline__ void quad_stage(T* x, T& v, T u0, T dtau, const QuadLane& Q, const Math& mc,
+                                                    bool* bad) {
+    if constexpr (SLOW) {
+      quad_advance(x, u0, dtau, v, Q);
+      v = quad_trig<true>(x, Q, mc, bad);
+    } else {
+      const T x0n = __builtin_fma(dtau, x[2], x[0]);  CGM_SB();
+      const T x1n = __builtin_fma(dtau, x[3], x[1]);  CGM_SB();
+      const T m1 = __builtin_fma(Q.mp, x[2], Q.mq);   CGM_SB();
+      const T d = x0n - x1n;                          CGM_SB();
+      const T m2 = __builtin_fma(Q.mr, u0, Q.ms);     CGM_SB();
+      const T arg = Q.second_angle ? x1n : d;         CGM_SB();
+      const T m = __builtin_fma(m1, x[2], m2);        CGM_SB();
+      const T t = arg * mc.inv_pio2;                  CGM_SB();
+      const T mv = mul2(m, v);  /* not contractible: the quad sum must see the same rounded product in every lane */  CGM_SB();
+      const T n = __builtin_rint(t);                  CGM_SB();
+      const T dx23 = x[2] - x[3];                     CGM_SB();
+      const T r1 = __builtin_fma(-n, mc.pio2_hi, arg);  CGM_SB();
+      const T sw1 = dpp_move<DPP_QUAD_SWAP1>(mv);     CGM_SB();
+      const T r = __builtin_fma(-n, mc.pio2_lo, r1);  CGM_SB();
+      const int q = static_cast<int>(n);              CGM_SB();
+      const T s1 = mv + sw1;                          CGM_SB();
+      const T z = r * r;                              CGM_SB();
+      const T f2a = Bs * u0;                          CGM_SB();
+      T P = fma3(z, Q.c6, Q.c5);                      CGM_SB();
+      const T w = __builtin_fma(T(-0.5), z, T(1.0));  CGM_SB();
+      const T sw2 = dpp_move<DPP_QUAD_SWAP2>(s1);     CGM_SB();
+      P = fma3(z, P, Q.c4);                           CGM_SB();
+      const T tsel = Q.is_cos ? z : r;                CGM_SB();
+      const T trig_sum = s1 + sw2;                    CGM_SB();
+      P = fma3(z, P, Q.c3);                           CGM_SB();
+      const T asel = Q.is_cos ? w : r;                CGM_SB();
+      const T f3 = __builtin_fma(C22, dx23, trig_sum);  CGM_SB();
+      P = fma3(z, P, Q.c2);                           CGM_SB();
+      const T zt = z * tsel;                          CGM_SB();
+      const T f2 = __builtin_fma(-As, x[2], f2a);     CGM_SB();
+      const T x3n = __builtin_fma(dtau, f3, x[3]);    CGM_SB();
+      P = fma3(z, P, Q.c1);                           CGM_SB();
+      const T x2n = __builtin_fma(dtau, f2, x[2]);    CGM_SB();
+      *bad = *bad || !(__builtin_fabs(arg) < T(1.0e5));  CGM_SB();
+      const T mine = fma3(zt, P, asel);               CGM_SB();
+      const bool odd = q & 1;
+      const int flip = ((q + (Q.is_cos ? 1 : 0)) & 2) << 30;  CGM_SB();
+      const T other = dpp_move<DPP_QUAD_SWAP1>(mine); CGM_SB();
+      const T pick = odd ? other : mine;
+      v = __hiloint2double(__double2hiint(pick) ^ flip, __double2loint(pick));
+      x[0] = x0n, x[1] = x1n, x[2] = x2n, x[3] = x3n;
+    }
+  }
+#undef CGM_SB
   static __device__ __forceinline__ void ddHduu(T* m, const T*, const T* u, const T*, const T*) {  // :64-76
     m[0] = r0 + 2 * u[2];
     m[1] = 0;

@@ -87,12 +87,12 @@ struct WgLds {
   // stage table: NSTG values per (stage, instance), layout [stage][slot][IPW]
   //   after phase 1: slots 0..NX-1 = x(s), NX..NX+NC-1 = trig(s);  after phase 2: slots 0..NBW-1 = costate coefficients
   static constexpr int NSTG = (M::NX + M::NC) > M::NBW ? (M::NX + M::NC) : M::NBW;
-  T *U, *Fh, *W, *R, *p, *H, *rho, *g, *xs, *xh, *xT;  // xT: terminal state of the last state sweep
+  T *U, *Fh, *W, *R, *p, *H, *rho, *g, *xs, *xh, *xT, *dum;  // xT: terminal states; dum: sink of unused stores
   int *flag, *reason, *nax, *ksolve;
   static __host__ __device__ size_t count_T(int dv, int kmax, int Lp, int Pp, int Hp) {
     const int k1 = kmax + 1;
     return size_t(3) * IPW * Lp + size_t(dv) * NSTG * IPW + size_t(IPW) * Pp + size_t(IPW) * Hp + size_t(IPW) * k1 +
-           size_t(IPW) * 3 * kmax + size_t(5) * M::NX * IPW;
+           size_t(IPW) * 3 * kmax + size_t(5) * M::NX * IPW + IPW;
   }
   static __host__ __device__ size_t bytes(int dv, int kmax, int Lp, int Pp, int Hp) {
     return count_T(dv, kmax, Lp, Pp, Hp) * sizeof(T) + 4 * IPW * sizeof(int) + 16;
@@ -111,6 +111,7 @@ struct WgLds {
     xs = q, q += M::NX * IPW;
     xh = q, q += M::NX * IPW;
     xT = q, q += 3 * M::NX * IPW;  // three terminal states: the preamble sweeps run concurrently
+    dum = q, q += IPW;
     int* z = reinterpret_cast<int*>(q);
     flag = z, reason = z + IPW, nax = z + 2 * IPW, ksolve = z + 3 * IPW;
   }
@@ -237,7 +238,7 @@ struct WgCtx {
 
   // phase 1: state sweep, cgmres.hpp:132-140, on the lanes [lane0, lane0 + 64) of one wave; x(dv) -> xT[c*IPW + i]
   template <bool PERT>
-  __device__ __forceinline__ void sweep_state(int lane0, const T* x0c, T dtau, T* tab, T* xT, bool only_active) {
+  __device__ __forceinline__ void sweep_state(int lane0, const T* x0c, T dtau, T* tab, T* dummy, T* xT, bool only_active) {
     constexpr int NX = M::NX, NU = M::NU, NC = M::NC;
     const int dv = P.dv, lt = tid - lane0;
     if (lt < 0 || lt >= 64) return;
@@ -260,16 +261,23 @@ struct WgCtx {
 #pragma unroll
           for (int c = 0; c < NX; ++c) x[c] = x0c[c * IPW + qi];
           T v = M::template quad_trig<SLOW>(x, Q, mc, &bad);
+          // No branch inside the stage: every lane of the quad stores the (replicated) state, lane 2's unused
+          // trig value goes to a dummy word, and u0 of the next stage is fetched one stage ahead (index dv*NU is
+          // the pad word of the odd-pitch row).  One basic block => exact lgkmcnt waits and a schedulable stage.
+          T* px = R;
+          T* pv = Q.trig_slot >= 0 ? R + Q.trig_slot * IPW : dummy + qi;
+          const int vstep = Q.trig_slot >= 0 ? NSTG * IPW : 0;
+          T un = U[0], wn = PERT ? W[0] : T(0);
           for (int s = 0; s < dv; ++s) {
-            T u0 = U[s * NU];
-            if (PERT) u0 = W[s * NU] * P.h + u0;
-            if (rho == 0) {
+            T u0 = un;
+            if (PERT) u0 = wn * P.h + u0;
+            un = U[(s + 1) * NU];
+            if (PERT) wn = W[(s + 1) * NU];
 #pragma unroll
-              for (int c = 0; c < NX; ++c) R[(s * NSTG + c) * IPW] = x[c];
-            }
-            if (Q.trig_slot >= 0) R[(s * NSTG + Q.trig_slot) * IPW] = v;
-            M::quad_advance(x, u0, dtau, v, Q);
-            v = M::template quad_trig<SLOW>(x, Q, mc, &bad);
+            for (int c = 0; c < NX; ++c) px[c * IPW] = x[c];
+            *pv = v;
+            px += NSTG * IPW, pv += vstep;
+            M::template quad_stage<SLOW>(x, v, u0, dtau, Q, mc, &bad);
           }
           return bad;
         };
@@ -396,7 +404,7 @@ struct WgCtx {
   // inside); the caller adds the barrier that publishes `out`.  x0c = initial state, component-major LDS [c*IPW + i].
   template <bool PERT, int MODE>
   __device__ __forceinline__ void f_eval(const T* x0c, T dtau, T* out, bool only_active) {
-    sweep_state<PERT>(0, x0c, dtau, S.R, S.xT, only_active);
+    sweep_state<PERT>(0, x0c, dtau, S.R, S.dum, S.xT, only_active);
     __syncthreads();
     CGM_STAMP(*this, 4);
     sweep_coeffs<PERT, MODE>(dtau, S.R, out, only_active);
@@ -435,10 +443,11 @@ struct WgCtx {
       const size_t tab_n = size_t(P.dv) * NSTG * IPW;
       T* tab0 = P.scr + size_t(blockIdx.x) * 2 * tab_n;
       T* tab1 = tab0 + tab_n;
+      T* gdum = P.scr + size_t(gridDim.x) * 2 * tab_n + size_t(blockIdx.x) * IPW;  // sink, see sweep_state
       T* xT0 = S.xT, *xT1 = S.xT + M::NX * IPW, *xT2 = S.xT + 2 * M::NX * IPW;
-      sweep_state<false>(0, S.xh, P.dtau_h, S.R, xT0, false);
-      sweep_state<false>(64, S.xs, P.dtau_0, tab0, xT1, false);
-      if (WITH_AX0) sweep_state<true>(128, S.xh, P.dtau_h, tab1, xT2, false);
+      sweep_state<false>(0, S.xh, P.dtau_h, S.R, S.dum, xT0, false);
+      sweep_state<false>(64, S.xs, P.dtau_0, tab0, gdum, xT1, false);
+      if (WITH_AX0) sweep_state<true>(128, S.xh, P.dtau_h, tab1, gdum, xT2, false);
       __threadfence_block();
       __syncthreads();  // drains vmcnt: the HBM tables are complete and visible to the other waves of this CU
       CGM_STAMP(*this, 4);
