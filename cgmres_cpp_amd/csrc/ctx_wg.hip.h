@@ -1,6 +1,7 @@
 // Host side of the "wg" mapping (tick_wg.hip.h): owns the instance-major HBM state of the batch,
 // computes the batch-wide scalars of each tick (t, dtau) and launches one kernel per control tick.
 #pragma once
+#include <vector>
 #include "ctx_common.hip.h"
 #include "tick_wg.hip.h"
 #include "util_kernels.hip.h"
@@ -211,7 +212,18 @@ struct CtxWg final : cgmres_hip_ctx {
   int get_krylov(void* V, void* H, void* rho, void* g) override {
     HIP_TRY(hipSetDevice(cfg.device));
     const int k1 = cfg.k_max + 1;
-    if (int rc = rows_d2h(V, P.V, P.Lv, L, size_t(cfg.batch) * k1)) return rc;
+    if (V) {  // rows are pair-interleaved on the device (WgCtx::load_vec): element r + 16 m sits at (m/2)*32 + 2r + (m&1)
+      const size_t rows = size_t(cfg.batch) * k1;
+      std::vector<T> tmp(rows * P.Lv);
+      HIP_TRY(hipMemcpyAsync(tmp.data(), P.V, tmp.size() * sizeof(T), hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+      T* dst = static_cast<T*>(V);
+      for (size_t q = 0; q < rows; ++q)
+        for (int e = 0; e < L; ++e) {
+          const int rr = e & 15, m = e >> 4;
+          dst[q * L + e] = tmp[q * P.Lv + (m >> 1) * 32 + 2 * rr + (m & 1)];
+        }
+    }
     if (H)
       if (int rc = rows_d2h(H, P.kry, ks_all, k1 * k1, cfg.batch)) return rc;
     if (rho)

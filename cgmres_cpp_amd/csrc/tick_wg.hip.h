@@ -186,13 +186,25 @@ struct WgCtx {
   // them and all later operations are linear), so neither direction needs a guard.  That matters for more than the
   // compare: a guarded load is an exec-masked branch, and the compiler cannot count outstanding loads across
   // branches — every wait in the Gram-Schmidt rounds became vmcnt(0) and serialised the register ring.
+  // In HBM a Krylov row is stored pair-interleaved — element (r + 16 m) at (m/2)*32 + 2r + (m&1) — so a lane moves
+  // two of its elements per 16-byte access: half the vector-memory instructions (the CU's address unit takes ~16
+  // cycles per 64-lane access and four waves issue their rows at once).  ctx_wg undoes the permutation on export.
+  struct alignas(2 * sizeof(T)) Pair {
+    T a, b;
+  };
+  static_assert(MAXM % 2 == 0, "pair-interleaved Krylov rows");
   __device__ __forceinline__ void load_vec(T* reg, const T* row) const {
+    const Pair* q = reinterpret_cast<const Pair*>(row) + r;
 #pragma unroll
-    for (int m = 0; m < MAXM; ++m) reg[m] = row[elem(m)];
+    for (int m = 0; m < MAXM; m += 2) {
+      const Pair t = q[(m / 2) * 16];
+      reg[m] = t.a, reg[m + 1] = t.b;
+    }
   }
   __device__ __forceinline__ void store_vec(T* row, const T* reg) const {
+    Pair* q = reinterpret_cast<Pair*>(row) + r;
 #pragma unroll
-    for (int m = 0; m < MAXM; ++m) row[elem(m)] = reg[m];
+    for (int m = 0; m < MAXM; m += 2) q[(m / 2) * 16] = Pair{reg[m], reg[m + 1]};
   }
 
   // Common prologue: U, ptau -> LDS; x -> LDS (component-major); flags cleared.  All global loads of the row are
@@ -542,7 +554,17 @@ struct WgCtx {
     int k = 0;
     for (; k < kmax; ++k) {  // gmres.hpp:46
       CGM_STAMP(*this, 14);
-      if (!__syncthreads_or(active ? 1 : 0)) break;  // also publishes W / flag to the sweep lanes
+      // Workgroup barrier that orders LDS only (W and the flags are what the sweep lanes need).  __syncthreads()
+      // would also drain this wave's HBM store of the new basis row (s_waitcnt vmcnt(0)) — nobody else reads it.
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+      {
+        int any = 0;
+#pragma unroll
+        for (int j = 0; j < IPW; ++j) any |= S.flag[j];
+        if (!any) break;
+      }
       CGM_STAMP(*this, 15);
       // The first basis vectors this iteration needs are requested from HBM/L2 NOW: they arrive while wave 0 sweeps.
       T vbuf[NBUF][MAXM];
@@ -666,6 +688,13 @@ struct WgCtx {
     // natural exit: every column is used
     const int reason = S.reason[inst];
     const int ks = reason == 0 ? (valid ? kmax : 0) : (reason == 1 ? S.ksolve[inst] : 0);
+    // the first basis rows of the x update are requested before the (serial) back substitution
+    T vbx[NBUF][MAXM];
+    if (preload && valid && reason <= 1) {
+#pragma unroll
+      for (int j = 0; j < NBUF; ++j)
+        if (j < ks) load_vec(vbx[j], vrow(j));
+    }
     if (valid && reason <= 1) {
       // back substitution (gmres.hpp:100-107): lane 0 of the row, in LDS
       if (r == 0) {
@@ -685,10 +714,7 @@ struct WgCtx {
 #pragma unroll
       for (int m = 0; m < MAXM; ++m) acc[m] = T(0.0);
       if (preload) {  // same register ring as the Gram-Schmidt rounds
-        T vbuf[NBUF][MAXM];
-#pragma unroll
-        for (int j = 0; j < NBUF; ++j)
-          if (j < ks) load_vec(vbuf[j], vrow(j));
+        auto& vbuf = vbx;
         auto rounds = [&](auto kc) {
           constexpr int K = decltype(kc)::value;
 #pragma unroll
