@@ -229,131 +229,93 @@ struct PendulumDev {
     l[0] = n0, l[1] = n1, l[2] = n2, l[3] = n3;
   }
   // --- state sweep over a DPP quad (fp64 only) -----------------------------------------------------------------
-  // With one wave per SIMD an fp64 op issues every ~8 cycles and the serial state sweep (2 sincos + ~17 flops per
-  // stage) is the longest phase of a tick.  Here the four lanes of a quad carry ONE instance: all four hold the same
-  // x, lane rho evaluates one of the four polynomial kernels {sin d, cos d, sin x1, cos x1} (d = x0 - x1) through a
-  // single instruction stream (per-lane coefficient sets, A + B*P form for both kernels), the sin/cos pair of an
-  // angle is exchanged with quad_perm[1,0,3,2] for the quadrant fix-up, and the trig-dependent part of dxdt[3]
-  //      A32 x2^2 sin d  +  (A32a x2 - A32b u0) cos d  +  A52 sin x1          (model.hpp:41, regrouped)
-  // is one multiply per lane + a quad sum, bit-identical in the four lanes, so x stays replicated without any
-  // broadcast.  30 fp64 ops per stage and lane instead of 51.  Stage table writes: lane 0 stores x(s), lanes 0,1,3
-  // store sin d, cos d, cos x1.
+  // The serial state sweep (2 sincos + ~17 flops per stage, model.hpp:37-42) is the longest phase of a tick, and one
+  // wave issues ONE instruction of any kind per ~4.4 cycles, dependent or not (tools/ubench_issue.hip; a taken
+  // branch costs 28 more) — so what counts is the number of instructions per stage, not their latency.
+  // Here the four lanes of a quad carry ONE instance and share a single instruction stream:
+  //   * lane rho evaluates one of the four kernels {sin d, cos d, sin x1, cos x1} (d = x0 - x1) with per-lane
+  //     coefficients in the common form  G = 1 + z*P(z),  value = G*h  (sin: P = S1..S6, h = r;  cos: P = -1/2 +
+  //     z*(C1..C6), h = 1), no select inside the kernel; the sin/cos pair of an angle is exchanged with
+  //     quad_perm[1,0,3,2] for the quadrant fix-up;
+  //   * the d-lanes keep -x1 instead of x1, so the angle of every lane is ONE fma: arg = kap*x0 + x1c;
+  //   * the trig-dependent part of dxdt[3],  A32 x2^2 sin d + (A32a x2 - A32b u0) cos d + A52 sin x1  (model.hpp:41,
+  //     regrouped), is one multiply per lane + a quad sum, bit-identical in the four lanes, so x stays replicated
+  //     without any broadcast.
+  // Stage-table writes (all lanes, no branch): x0,x2 -> slots 0,2 (same value from every lane); this lane's x1c
+  // -> slot 1 from the x1-lanes, slot 3 from the d-lanes; the trig value -> slots 4 (sin d), 5 (cos d), 6 (cos x1)
+  // and 3 (sin x1).  Slot 3 (x3) is never read: stage_coeffs does not use x[3] because q3 = 0.
   static constexpr bool HAS_QUAD_SWEEP = sizeof(T) == 8;
+  static constexpr int QSLOT_XA = 0, QSLOT_XB = 2, QLANE_TRUE_X = 2;  // write2 slots; a lane whose x[1] is +x1
   struct QuadLane {
-    T c1, c2, c3, c4, c5, c6;  // polynomial coefficients of this lane's kernel (sin: S1..S6, cos: C1..C6)
-    T mp, mq, mr, ms;          // this lane's weight  (mp*x2 + mq)*x2 + (mr*u0 + ms)  of its trig value in dxdt[3]
-    bool is_cos, second_angle;
-    int trig_slot;             // stage-table slot of this lane's value (-1: not stored)
+    T k0, k1, k2, k3, k4, k5, k6;  // P(z) = k0 + z*(k1 + ... + z*k6)
+    T hs, hc;                      // h = hs*r + hc
+    T mp, mq, mr, ms;              // weight (mp*x2 + mq)*x2 + (mr*u0 + ms) of this lane's trig value in dxdt[3]
+    T kap, sg;                     // arg = kap*x0 + x1c, x1c = sg*x1
+    bool is_cos;
+    int slot_x1, slot_v;
     __device__ __forceinline__ void init(int rho, const Math& mc) {
-      is_cos = rho & 1, second_angle = rho >= 2;
-      c1 = is_cos ? mc.C1 : mc.S1, c2 = is_cos ? mc.C2 : mc.S2, c3 = is_cos ? mc.C3 : mc.S3;
-      c4 = is_cos ? mc.C4 : mc.S4, c5 = is_cos ? mc.C5 : mc.S5, c6 = is_cos ? mc.C6 : mc.S6;
+      is_cos = rho & 1;
+      k0 = is_cos ? T(-0.5) : mc.S1, k1 = is_cos ? mc.C1 : mc.S2, k2 = is_cos ? mc.C2 : mc.S3;
+      k3 = is_cos ? mc.C3 : mc.S4, k4 = is_cos ? mc.C4 : mc.S5, k5 = is_cos ? mc.C5 : mc.S6;
+      k6 = is_cos ? mc.C6 : T(0);
+      hs = is_cos ? T(0) : T(1), hc = is_cos ? T(1) : T(0);
       mp = rho == 0 ? A32 : T(0), mq = rho == 1 ? A32a : T(0), mr = rho == 1 ? -A32b : T(0), ms = rho == 2 ? A52 : T(0);
-      trig_slot = rho == 0 ? NX : (rho == 1 ? NX + 1 : (rho == 3 ? NX + 2 : -1));
+      kap = rho < 2 ? T(1) : T(0), sg = rho < 2 ? T(-1) : T(1);
+      slot_x1 = rho < 2 ? 3 : 1;
+      slot_v = rho == 0 ? NX : (rho == 1 ? NX + 1 : (rho == 2 ? 3 : NX + 2));
     }
   };
-  // The stage is split in two so the sweep loop can overlap consecutive stages: fp64 ops have an 8-cycle dependent
-  // latency but issue every ~4.4 cycles (tools/ubench_fp64.hip), and the angles of stage s+1 depend on x3(s) only
-  // through x1(s+1) = x1(s) + dtau*x3(s), not on dxdt[3](s).  quad_trig(x) is the long chain (reduction, Horner,
-  // quadrant fix-up); quad_advance(x, v) consumes its result.  Both are branch-free: arguments outside the fast range
-  // only set *bad, and the caller redoes the sweep with SLOW = true (library sin/cos) in that case.
+  // this lane's trig value of `arg`; *amax accumulates max|arg| (arguments outside the fast range make the caller
+  // redo the sweep with SLOW = true, the library sin/cos)
   template <bool SLOW>
-  static __device__ __forceinline__ T quad_trig(const T* x, const QuadLane& Q, const Math& mc, bool* bad) {
-    const T arg = Q.second_angle ? x[1] : x[0] - x[1];
-    if (SLOW) {
+  static __device__ __forceinline__ T quad_trig(T arg, const QuadLane& Q, const Math& mc, T* amax) {
+    if constexpr (SLOW) {
       double sn, cs;
       ::sincos(double(arg), &sn, &cs);
       return Q.is_cos ? T(cs) : T(sn);
+    } else {
+      *amax = __builtin_fmax(*amax, __builtin_fabs(arg));
+      const T n = __builtin_rint(arg * mc.inv_pio2);
+      T r = __builtin_fma(-n, mc.pio2_hi, arg);
+      r = __builtin_fma(-n, mc.pio2_lo, r);
+      const int q = static_cast<int>(n);
+      const T z = r * r;
+      T P = fma3(z, Q.k6, Q.k5);
+      P = fma3(z, P, Q.k4);
+      P = fma3(z, P, Q.k3);
+      P = fma3(z, P, Q.k2);
+      P = fma3(z, P, Q.k1);
+      P = fma3(z, P, Q.k0);
+      const T G = __builtin_fma(z, P, T(1.0));
+      const T h = fma3(Q.hs, r, Q.hc);
+      const T mine = mul2(G, h);
+      const T other = dpp_move<DPP_QUAD_SWAP1>(mine);  // the cos kernel of my angle if I am the sin lane, and v.v.
+      const T pick = (q & 1) ? other : mine;            // sin = {s,c,-s,-c}[q&3], cos = {c,-s,-c,s}[q&3]
+      const int flip = ((q + (Q.is_cos ? 1 : 0)) & 2) << 30;
+      return __hiloint2double(__double2hiint(pick) ^ flip, __double2loint(pick));
     }
-    *bad = *bad || !(__builtin_fabs(arg) < T(1.0e5));  // also NaN
-    const T n = __builtin_rint(arg * mc.inv_pio2);
-    T r = __builtin_fma(-n, mc.pio2_hi, arg);
-    r = __builtin_fma(-n, mc.pio2_lo, r);
-    const int q = static_cast<int>(n);
-    const T z = r * r;
-    T P = fma3(z, Q.c6, Q.c5);
-    P = fma3(z, P, Q.c4);
-    P = fma3(z, P, Q.c3);
-    P = fma3(z, P, Q.c2);
-    P = fma3(z, P, Q.c1);
-    const T w = __builtin_fma(T(-0.5), z, T(1.0));
-    const T t = Q.is_cos ? z : r;  // sin: r + (z r) P      cos: (1 - z/2) + (z z) P
-    const T a = Q.is_cos ? w : r;
-    const T mine = fma3(z * t, P, a);
-    const T other = dpp_move<DPP_QUAD_SWAP1>(mine);  // the cos kernel of my angle if I am the sin lane, and v.v.
-    const T pick = (q & 1) ? other : mine;            // sin = {s,c,-s,-c}[q&3], cos = {c,-s,-c,s}[q&3]
-    const int flip = ((q + (Q.is_cos ? 1 : 0)) & 2) << 30;
-    return __hiloint2double(__double2hiint(pick) ^ flip, __double2loint(pick));
   }
-  // x (replicated in the quad) -> x + dtau*dxdt(x, u0), v = this lane's trig value of the CURRENT x
-  static __device__ __forceinline__ void quad_advance(T* x, T u0, T dtau, T v, const QuadLane& Q) {
+  static __device__ __forceinline__ bool quad_arg_bad(T amax) { return !(amax < T(1.0e5)); }
+  // lane-local form of the state (x[1] <- sg*x1) and the first trig value
+  template <bool SLOW>
+  static __device__ __forceinline__ T quad_begin(T* x, const QuadLane& Q, const Math& mc, T* amax) {
+    x[1] = Q.sg * x[1];
+    return quad_trig<SLOW>(__builtin_fma(Q.kap, x[0], x[1]), Q, mc, amax);
+  }
+  // One stage: x(s), v = trig(x(s)) -> x(s+1), v = trig(x(s+1)).  dtau1 = sg*dtau.
+  template <bool SLOW>
+  static __device__ __forceinline__ void quad_stage(T* x, T& v, T u0, T dtau, T dtau1, const QuadLane& Q,
+                                                    const Math& mc, T* amax) {
     const T m = __builtin_fma(__builtin_fma(Q.mp, x[2], Q.mq), x[2], __builtin_fma(Q.mr, u0, Q.ms));
-    const T trig_sum = quad_sum(m * v);
+    const T trig_sum = quad_sum(mul2(m, v));  // mul2: the same rounded product in every lane of the quad
     const T f3 = __builtin_fma(C22, x[2] - x[3], trig_sum);
     const T f2 = __builtin_fma(-As, x[2], Bs * u0);
     x[0] = __builtin_fma(dtau, x[2], x[0]);
-    x[1] = __builtin_fma(dtau, x[3], x[1]);
+    x[1] = __builtin_fma(dtau1, x[3], x[1]);
     x[2] = __builtin_fma(dtau, f2, x[2]);
     x[3] = __builtin_fma(dtau, f3, x[3]);
+    v = quad_trig<SLOW>(__builtin_fma(Q.kap, x[0], x[1]), Q, mc, amax);
   }
-  // One whole stage, hand-scheduled: x(s), v = trig(x(s)) -> x(s+1), v = trig(x(s+1)).  Same arithmetic as
-  // quad_advance followed by quad_trig, but issued in an explicit order that alternates the long chain (the trig of
-  // stage s+1, 17 dependent levels) with the short one (dxdt[3] of stage s, which needs the trig of stage s): a
-  // wave64 fp64 op issues in 4 cycles and its result is ready after 8, so every dependent pair needs exactly one
-  // independent instruction in between.  Left to itself hipcc emits the two chains one after the other (~430
-  // cycles/stage measured; the issue bound of the ~60 instructions is ~240).  CGM_SB pins the order.
-#define CGM_SB() __builtin_amdgcn_sched_barrier(0)
-  template <bool SLOW>
-  static __device__ __forceinline__ void quad_stage(T* x, T& v, T u0, T dtau, const QuadLane& Q, const Math& mc,
-                                                    bool* bad) {
-    if constexpr (SLOW) {
-      quad_advance(x, u0, dtau, v, Q);
-      v = quad_trig<true>(x, Q, mc, bad);
-    } else {
-      const T x0n = __builtin_fma(dtau, x[2], x[0]);  CGM_SB();
-      const T x1n = __builtin_fma(dtau, x[3], x[1]);  CGM_SB();
-      const T m1 = __builtin_fma(Q.mp, x[2], Q.mq);   CGM_SB();
-      const T d = x0n - x1n;                          CGM_SB();
-      const T m2 = __builtin_fma(Q.mr, u0, Q.ms);     CGM_SB();
-      const T arg = Q.second_angle ? x1n : d;         CGM_SB();
-      const T m = __builtin_fma(m1, x[2], m2);        CGM_SB();
-      const T t = arg * mc.inv_pio2;                  CGM_SB();
-      const T mv = mul2(m, v);  /* not contractible: the quad sum must see the same rounded product in every lane */  CGM_SB();
-      const T n = __builtin_rint(t);                  CGM_SB();
-      const T dx23 = x[2] - x[3];                     CGM_SB();
-      const T r1 = __builtin_fma(-n, mc.pio2_hi, arg);  CGM_SB();
-      const T sw1 = dpp_move<DPP_QUAD_SWAP1>(mv);     CGM_SB();
-      const T r = __builtin_fma(-n, mc.pio2_lo, r1);  CGM_SB();
-      const int q = static_cast<int>(n);              CGM_SB();
-      const T s1 = mv + sw1;                          CGM_SB();
-      const T z = r * r;                              CGM_SB();
-      const T f2a = Bs * u0;                          CGM_SB();
-      T P = fma3(z, Q.c6, Q.c5);                      CGM_SB();
-      const T w = __builtin_fma(T(-0.5), z, T(1.0));  CGM_SB();
-      const T sw2 = dpp_move<DPP_QUAD_SWAP2>(s1);     CGM_SB();
-      P = fma3(z, P, Q.c4);                           CGM_SB();
-      const T tsel = Q.is_cos ? z : r;                CGM_SB();
-      const T trig_sum = s1 + sw2;                    CGM_SB();
-      P = fma3(z, P, Q.c3);                           CGM_SB();
-      const T asel = Q.is_cos ? w : r;                CGM_SB();
-      const T f3 = __builtin_fma(C22, dx23, trig_sum);  CGM_SB();
-      P = fma3(z, P, Q.c2);                           CGM_SB();
-      const T zt = z * tsel;                          CGM_SB();
-      const T f2 = __builtin_fma(-As, x[2], f2a);     CGM_SB();
-      const T x3n = __builtin_fma(dtau, f3, x[3]);    CGM_SB();
-      P = fma3(z, P, Q.c1);                           CGM_SB();
-      const T x2n = __builtin_fma(dtau, f2, x[2]);    CGM_SB();
-      *bad = *bad || !(__builtin_fabs(arg) < T(1.0e5));  CGM_SB();
-      const T mine = fma3(zt, P, asel);               CGM_SB();
-      const bool odd = q & 1;
-      const int flip = ((q + (Q.is_cos ? 1 : 0)) & 2) << 30;  CGM_SB();
-      const T other = dpp_move<DPP_QUAD_SWAP1>(mine); CGM_SB();
-      const T pick = odd ? other : mine;
-      v = __hiloint2double(__double2hiint(pick) ^ flip, __double2loint(pick));
-      x[0] = x0n, x[1] = x1n, x[2] = x2n, x[3] = x3n;
-    }
-  }
-#undef CGM_SB
   static __device__ __forceinline__ void ddHduu(T* m, const T*, const T* u, const T*, const T*) {  // :64-76
     m[0] = r0 + 2 * u[2];
     m[1] = 0;

@@ -87,12 +87,12 @@ struct WgLds {
   // stage table: NSTG values per (stage, instance), layout [stage][slot][IPW]
   //   after phase 1: slots 0..NX-1 = x(s), NX..NX+NC-1 = trig(s);  after phase 2: slots 0..NBW-1 = costate coefficients
   static constexpr int NSTG = (M::NX + M::NC) > M::NBW ? (M::NX + M::NC) : M::NBW;
-  T *U, *Fh, *W, *R, *p, *H, *rho, *g, *xs, *xh, *xT, *dum;  // xT: terminal states; dum: sink of unused stores
+  T *U, *Fh, *W, *R, *p, *H, *rho, *g, *xs, *xh, *xT;  // xT: terminal state of the last state sweep
   int *flag, *reason, *nax, *ksolve;
   static __host__ __device__ size_t count_T(int dv, int kmax, int Lp, int Pp, int Hp) {
     const int k1 = kmax + 1;
     return size_t(3) * IPW * Lp + size_t(dv) * NSTG * IPW + size_t(IPW) * Pp + size_t(IPW) * Hp + size_t(IPW) * k1 +
-           size_t(IPW) * 3 * kmax + size_t(5) * M::NX * IPW + IPW;
+           size_t(IPW) * 3 * kmax + size_t(5) * M::NX * IPW;
   }
   static __host__ __device__ size_t bytes(int dv, int kmax, int Lp, int Pp, int Hp) {
     return count_T(dv, kmax, Lp, Pp, Hp) * sizeof(T) + 4 * IPW * sizeof(int) + 16;
@@ -111,7 +111,6 @@ struct WgLds {
     xs = q, q += M::NX * IPW;
     xh = q, q += M::NX * IPW;
     xT = q, q += 3 * M::NX * IPW;  // three terminal states: the preamble sweeps run concurrently
-    dum = q, q += IPW;
     int* z = reinterpret_cast<int*>(q);
     flag = z, reason = z + IPW, nax = z + 2 * IPW, ksolve = z + 3 * IPW;
   }
@@ -250,7 +249,7 @@ struct WgCtx {
 
   // phase 1: state sweep, cgmres.hpp:132-140, on the lanes [lane0, lane0 + 64) of one wave; x(dv) -> xT[c*IPW + i]
   template <bool PERT>
-  __device__ __forceinline__ void sweep_state(int lane0, const T* x0c, T dtau, T* tab, T* dummy, T* xT, bool only_active) {
+  __device__ __forceinline__ void sweep_state(int lane0, const T* x0c, T dtau, T* tab, T* xT, bool only_active) {
     constexpr int NX = M::NX, NU = M::NU, NC = M::NC;
     const int dv = P.dv, lt = tid - lane0;
     if (lt < 0 || lt >= 64) return;
@@ -263,38 +262,46 @@ struct WgCtx {
         Q.init(rho, mc);
         const T* __restrict__ U = S.U + qi * P.Lp;
         const T* W = S.W + qi * P.Lp;
-        T* __restrict__ R = tab + qi;
         T x[NX];
-        // one branch-free block per stage: store x(s) and its trig value, advance to x(s+1), start the trig of
-        // stage s+1 — the scheduler overlaps the trig chain of s+1 with the dxdt[3] chain of s
+        // Branch-free stages, two per loop trip: all lanes store (see the slot map in models.hip.h), u0 of the next
+        // stage is fetched one stage ahead (index dv*NU is the pad word of the odd-pitch row), and every table
+        // pointer advances by the same constant so the second stage of a trip addresses with immediates.
         auto sweep = [&](auto slow_tag) -> bool {
           constexpr bool SLOW = decltype(slow_tag)::value;
-          bool bad = false;
+          constexpr int STEP = NSTG * IPW;
+          T amax = T(0);
 #pragma unroll
           for (int c = 0; c < NX; ++c) x[c] = x0c[c * IPW + qi];
-          T v = M::template quad_trig<SLOW>(x, Q, mc, &bad);
-          // No branch inside the stage: every lane of the quad stores the (replicated) state, lane 2's unused
-          // trig value goes to a dummy word, and u0 of the next stage is fetched one stage ahead (index dv*NU is
-          // the pad word of the odd-pitch row).  One basic block => exact lgkmcnt waits and a schedulable stage.
-          T* px = R;
-          T* pv = Q.trig_slot >= 0 ? R + Q.trig_slot * IPW : dummy + qi;
-          const int vstep = Q.trig_slot >= 0 ? NSTG * IPW : 0;
-          T un = U[0], wn = PERT ? W[0] : T(0);
-          for (int s = 0; s < dv; ++s) {
-            T u0 = un;
-            if (PERT) u0 = wn * P.h + u0;
-            un = U[(s + 1) * NU];
-            if (PERT) wn = W[(s + 1) * NU];
-#pragma unroll
-            for (int c = 0; c < NX; ++c) px[c * IPW] = x[c];
-            *pv = v;
-            px += NSTG * IPW, pv += vstep;
-            M::template quad_stage<SLOW>(x, v, u0, dtau, Q, mc, &bad);
+          T v = M::template quad_begin<SLOW>(x, Q, mc, &amax);
+          T* pa = tab + qi;
+          T* pb = tab + qi + Q.slot_x1 * IPW;
+          T* pv = tab + qi + Q.slot_v * IPW;
+          const T* pu = U;
+          const T* pw = W;
+          const T dtau1 = Q.sg * dtau;
+          auto stage = [&](int o, T ur, T wr) {
+            T u0 = ur;
+            if (PERT) u0 = wr * P.h + u0;
+            pa[o * STEP + M::QSLOT_XA * IPW] = x[0];
+            pa[o * STEP + M::QSLOT_XB * IPW] = x[2];
+            pb[o * STEP] = x[1];
+            pv[o * STEP] = v;
+            M::template quad_stage<SLOW>(x, v, u0, dtau, dtau1, Q, mc, &amax);
+          };
+          T ua = pu[0], wa = PERT ? pw[0] : T(0);
+          int s = 0;
+          for (; s + 2 <= dv; s += 2) {
+            const T ub = pu[NU], wb = PERT ? pw[NU] : T(0);
+            stage(0, ua, wa);
+            ua = pu[2 * NU], wa = PERT ? pw[2 * NU] : T(0);
+            stage(1, ub, wb);
+            pa += 2 * STEP, pb += 2 * STEP, pv += 2 * STEP, pu += 2 * NU, pw += 2 * NU;
           }
-          return bad;
+          if (s < dv) stage(0, ua, wa);
+          return M::quad_arg_bad(amax);
         };
         if (__builtin_expect(__any(sweep(std::false_type{})), 0)) sweep(std::true_type{});
-        if (rho == 0) {
+        if (rho == M::QLANE_TRUE_X) {
 #pragma unroll
           for (int c = 0; c < NX; ++c) xT[c * IPW + qi] = x[c];
         }
@@ -416,7 +423,7 @@ struct WgCtx {
   // inside); the caller adds the barrier that publishes `out`.  x0c = initial state, component-major LDS [c*IPW + i].
   template <bool PERT, int MODE>
   __device__ __forceinline__ void f_eval(const T* x0c, T dtau, T* out, bool only_active) {
-    sweep_state<PERT>(0, x0c, dtau, S.R, S.dum, S.xT, only_active);
+    sweep_state<PERT>(0, x0c, dtau, S.R, S.xT, only_active);
     __syncthreads();
     CGM_STAMP(*this, 4);
     sweep_coeffs<PERT, MODE>(dtau, S.R, out, only_active);
@@ -455,11 +462,10 @@ struct WgCtx {
       const size_t tab_n = size_t(P.dv) * NSTG * IPW;
       T* tab0 = P.scr + size_t(blockIdx.x) * 2 * tab_n;
       T* tab1 = tab0 + tab_n;
-      T* gdum = P.scr + size_t(gridDim.x) * 2 * tab_n + size_t(blockIdx.x) * IPW;  // sink, see sweep_state
       T* xT0 = S.xT, *xT1 = S.xT + M::NX * IPW, *xT2 = S.xT + 2 * M::NX * IPW;
-      sweep_state<false>(0, S.xh, P.dtau_h, S.R, S.dum, xT0, false);
-      sweep_state<false>(64, S.xs, P.dtau_0, tab0, gdum, xT1, false);
-      if (WITH_AX0) sweep_state<true>(128, S.xh, P.dtau_h, tab1, gdum, xT2, false);
+      sweep_state<false>(0, S.xh, P.dtau_h, S.R, xT0, false);
+      sweep_state<false>(64, S.xs, P.dtau_0, tab0, xT1, false);
+      if (WITH_AX0) sweep_state<true>(128, S.xh, P.dtau_h, tab1, xT2, false);
       __threadfence_block();
       __syncthreads();  // drains vmcnt: the HBM tables are complete and visible to the other waves of this CU
       CGM_STAMP(*this, 4);

@@ -1,0 +1,104 @@
+// Micro-benchmark (dev tool): per-instruction issue cost seen by ONE wave on gfx950, measured with s_memtime
+// around loops of .rept-expanded inline assembly (64 instructions per taken branch, so the branch is amortised;
+// the branch itself is measured separately).
+//   hipcc --offload-arch=gfx950 -O3 -o _diag/ubench_issue tools/ubench_issue.hip && ./_diag/ubench_issue
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+#define REPT(n, body) ".rept " #n "\n" body "\n.endr\n"
+
+template <int TEST>
+__global__ void k(double* out, long long* cyc, int iters, double b, double c) {
+  double a = threadIdx.x * 1e-3 + 1.0, d = threadIdx.x * 2e-3 + 1.5, e = a + 3, f = d + 4;
+  int i0 = threadIdx.x, i1 = threadIdx.x * 3;
+  __shared__ double lds[1024];
+  lds[threadIdx.x] = a;
+  __syncthreads();
+  int addr = (threadIdx.x >> 2) * 8;
+  long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < iters; ++it) {
+    if (TEST == 0) asm volatile(REPT(64, "v_fma_f64 %0, %0, %1, %2") : "+v"(a) : "v"(b), "v"(c));
+    if (TEST == 1)
+      asm volatile(REPT(32, "v_fma_f64 %0, %0, %2, %3\n v_fma_f64 %1, %1, %2, %3") : "+v"(a), "+v"(d) : "v"(b), "v"(c));
+    if (TEST == 2)
+      asm volatile(REPT(16, "v_fma_f64 %0, %0, %4, %5\n v_fma_f64 %1, %1, %4, %5\n v_fma_f64 %2, %2, %4, %5\n v_fma_f64 %3, %3, %4, %5")
+                   : "+v"(a), "+v"(d), "+v"(e), "+v"(f) : "v"(b), "v"(c));
+    if (TEST == 3) asm volatile(REPT(64, "v_mul_f64 %0, %0, %1") : "+v"(a) : "v"(b));
+    if (TEST == 4) asm volatile(REPT(64, "v_add_f64 %0, %0, %1") : "+v"(a) : "v"(c));
+    if (TEST == 5) asm volatile(REPT(64, "v_rndne_f64 %0, %0") : "+v"(a));
+    if (TEST == 6) asm volatile(REPT(32, "v_cvt_i32_f64 %1, %0\n v_cvt_f64_i32 %0, %1") : "+v"(a), "+v"(i0));
+    if (TEST == 7) asm volatile(REPT(64, "v_cndmask_b32 %0, %0, %1, vcc") : "+v"(i0) : "v"(i1) : "vcc");
+    if (TEST == 8)
+      asm volatile(REPT(64, "v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n s_nop 1") : "+v"(i0));
+    if (TEST == 9)
+      asm volatile(REPT(32, "v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                            "v_mov_b32_dpp %1, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                   : "+v"(i0), "+v"(i1));  // independent-ish pairs: no nop needed between different registers? (hazard: see note)
+    if (TEST == 10) asm volatile(REPT(64, "v_add_u32 %0, %0, %1") : "+v"(i0) : "v"(i1));
+    if (TEST == 11) asm volatile(REPT(64, "v_bitop3_b32 %0, %0, %1, %1 bitop3:0x6c") : "+v"(i0) : "v"(i1));
+    if (TEST == 12) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));  // 1 instr per taken branch
+    if (TEST == 13) asm volatile(REPT(64, "ds_read_b64 %0, %1\n s_waitcnt lgkmcnt(0)") : "+v"(a) : "v"(addr) : "memory");
+    if (TEST == 14) asm volatile(REPT(64, "ds_write_b64 %1, %0") : : "v"(a), "v"(addr) : "memory");
+    if (TEST == 15) asm volatile(REPT(64, "ds_write2_b64 %1, %0, %0 offset1:16") : : "v"(a), "v"(addr) : "memory");
+    if (TEST == 16) asm volatile(REPT(64, "v_fma_f64 %0, %0, %1, %2") : "+v"(a) : "s"(b), "v"(c));
+    if (TEST == 17) asm volatile(REPT(32, "v_fma_f64 %0, %0, %2, %3\n v_cndmask_b32 %1, %1, %1, vcc") : "+v"(a), "+v"(i0) : "v"(b), "v"(c) : "vcc");
+    if (TEST == 18) asm volatile(REPT(64, "v_cmp_nlt_f64 vcc, |%0|, %1") : : "v"(a), "v"(b) : "vcc");
+    if (TEST == 19) asm volatile(REPT(64, "v_fmac_f64 %0, %1, %2") : "+v"(a) : "v"(b), "v"(c));
+    if (TEST == 20) asm volatile(REPT(32, "v_fma_f64 %0, %0, %1, %2\n s_nop 0") : "+v"(a) : "v"(b), "v"(c));
+    if (TEST == 21) asm volatile(REPT(64, "v_mov_b32 %0, %1") : "+v"(i0) : "v"(i1));
+    if (TEST == 22) asm volatile(REPT(64, "v_mov_b64 %0, %1") : "+v"(a) : "v"(d));
+    if (TEST == 23) asm volatile(REPT(64, "v_accvgpr_read_b32 %0, a0") : "+v"(i0));
+    if (TEST == 24) asm volatile(REPT(64, "s_add_u32 s20, s20, 1") : : : "s20", "scc");
+    if (TEST == 25) asm volatile(REPT(64, "v_readlane_b32 s20, %0, 3") : : "v"(i0) : "s20");
+  }
+  long long t1 = __builtin_readcyclecounter();
+  if (TEST == 14 || TEST == 15) __syncthreads();
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a + d + e + f + i0 + i1 + lds[(threadIdx.x * 7) & 1023];
+  if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
+}
+
+template <int TEST>
+void run(const char* name, int per_iter) {
+  double* out;
+  long long *cyc, h;
+  (void)hipMalloc(&out, 1 << 20);
+  (void)hipMalloc(&cyc, 8);
+  const int iters = 2000;
+  k<TEST><<<1, 64>>>(out, cyc, iters, 1.0000001, 1e-9);
+  k<TEST><<<1, 64>>>(out, cyc, iters, 1.0000001, 1e-9);
+  (void)hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
+  printf("%-58s %7.2f cycles/instr  (%d instr per taken branch)\n", name, double(h) / (double(iters) * per_iter), per_iter);
+  fflush(stdout);
+  (void)hipFree(out);
+  (void)hipFree(cyc);
+}
+
+int main() {
+  run<0>("v_fma_f64 dependent chain", 64);
+  run<1>("v_fma_f64 2 chains", 64);
+  run<2>("v_fma_f64 4 chains", 64);
+  run<16>("v_fma_f64 dependent, one SGPR source", 64);
+  run<19>("v_fmac_f64 dependent", 64);
+  run<20>("v_fma_f64 dependent + s_nop 0 (per pair)", 64);
+  run<3>("v_mul_f64 dependent", 64);
+  run<4>("v_add_f64 dependent", 64);
+  run<5>("v_rndne_f64 dependent", 64);
+  run<6>("v_cvt_i32_f64 / v_cvt_f64_i32 dependent", 64);
+  run<7>("v_cndmask_b32 dependent", 64);
+  run<17>("v_fma_f64 + v_cndmask_b32 alternating", 64);
+  run<18>("v_cmp_nlt_f64 -> vcc", 64);
+  run<8>("v_mov_b32_dpp quad_perm dependent + s_nop 1", 64);
+  run<9>("v_mov_b32_dpp ping-pong (no nop)", 64);
+  run<10>("v_add_u32 dependent", 64);
+  run<11>("v_bitop3_b32 dependent", 64);
+  run<21>("v_mov_b32", 64);
+  run<22>("v_mov_b64", 64);
+  run<23>("v_accvgpr_read_b32", 64);
+  run<24>("s_add_u32 dependent", 64);
+  run<25>("v_readlane_b32", 64);
+  run<12>("loop of 1 v_fma_f64 (taken branch cost)", 1);
+  run<13>("ds_read_b64 + wait (LDS latency)", 64);
+  run<14>("ds_write_b64 64 lanes, 4 lanes/address", 64);
+  run<15>("ds_write2_b64 64 lanes, 4 lanes/address", 64);
+  return 0;
+}
