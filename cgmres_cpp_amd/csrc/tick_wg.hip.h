@@ -389,34 +389,39 @@ struct WgCtx {
 #pragma unroll
     for (int j = 0; j < NP; ++j) p[j] = S.p[i * P.Pp + dv * NP + j];
     M::dPhidx(l, xs, p);
-    T* o = out + i * P.Lp;
-    const T* R = S.R + i;
-    // two register sets, unrolled by two: the LDS operands of stage s-1 are in flight while stage s computes
+    // Two stages per loop trip with two register sets: the LDS operands of the next stage are in flight while this
+    // one computes.  One wave issues one instruction per ~4.4 cycles whatever it is (tools/ubench_issue.hip), so the
+    // loop is written for instruction count: moving pointers with immediate offsets, no branch inside a trip, and the
+    // look-ahead fetch is unconditional (below stage 0 it reads words of the preceding LDS arrays, never used).
+    constexpr int STEP = NSTG * IPW;
     struct Ops {
       T bw[NBW], o[NUL];
     };
-    auto fetch = [&](Ops& a, int s) {
+    auto fetch = [&](Ops& a, const T* pr, const T* po) {
 #pragma unroll
-      for (int c = 0; c < NBW; ++c) a.bw[c] = R[(s * NSTG + c) * IPW];
+      for (int c = 0; c < NBW; ++c) a.bw[c] = pr[c * IPW];
 #pragma unroll
-      for (int j = 0; j < NUL; ++j) a.o[j] = o[s * NU + j];
+      for (int j = 0; j < NUL; ++j) a.o[j] = po[j];
     };
-    auto stage = [&](const Ops& a, int s) {
+    auto stage = [&](const Ops& a, T* po) {
       T dF[NUL];
       M::costate_step(l, dF, a.bw, dtau);
 #pragma unroll
-      for (int j = 0; j < NUL; ++j) o[s * NU + j] = a.o[j] + dF[j] * sc;
+      for (int j = 0; j < NUL; ++j) po[j] = a.o[j] + dF[j] * sc;
     };
     Ops A, B;
     int s = dv - 1;
-    fetch(A, s);
+    const T* pr = S.R + i + (dv - 2) * STEP;  // the lower stage of the current pair
+    T* po = out + i * P.Lp + (dv - 2) * NU;
+    fetch(A, pr + STEP, po + NU);
     for (; s >= 1; s -= 2) {
-      fetch(B, s - 1);
-      stage(A, s);
-      if (s >= 2) fetch(A, s - 2);
-      stage(B, s - 1);
+      fetch(B, pr, po);
+      stage(A, po + NU);
+      fetch(A, pr - STEP, po - NU);
+      stage(B, po);
+      pr -= 2 * STEP, po -= 2 * NU;
     }
-    if (s == 0) stage(A, 0);
+    if (s == 0) stage(A, po + NU);
   }
 
   // One complete sweep on the LDS table.  COLLECTIVE: every thread of the block must call it (two workgroup barriers
