@@ -224,8 +224,9 @@ struct PendulumDev {
     dF[0] = l[2] * Bs + bw[5] * l[3];
     const T n0 = (l[0] + bw[0]) + bw[1] * l[3];
     const T n1 = (l[1] + bw[2]) + bw[3] * l[3];
-    const T n2 = l[2] + (dtau * (l[0] - l[2] * As) + bw[4] * l[3]);
-    const T n3 = l[3] + dtau * (l[1] - l[3] * C22);
+    // (1 - dtau*As) and (1 - dtau*C22) are loop invariants of the sweep: 5 instructions for the two rows instead of 7
+    const T n2 = __builtin_fma(bw[4], l[3], __builtin_fma(dtau, l[0], (T(1.0) - dtau * As) * l[2]));
+    const T n3 = __builtin_fma(dtau, l[1], (T(1.0) - dtau * C22) * l[3]);
     l[0] = n0, l[1] = n1, l[2] = n2, l[3] = n3;
   }
   // --- state sweep over a DPP quad (fp64 only) -----------------------------------------------------------------
@@ -297,10 +298,11 @@ struct PendulumDev {
   }
   static __device__ __forceinline__ bool quad_arg_bad(T amax) { return !(amax < T(1.0e5)); }
   // lane-local form of the state (x[1] <- sg*x1) and the first trig value
+  static __device__ __forceinline__ T quad_arg(const T* x, const QuadLane& Q) { return __builtin_fma(Q.kap, x[0], x[1]); }
   template <bool SLOW>
   static __device__ __forceinline__ T quad_begin(T* x, const QuadLane& Q, const Math& mc, T* amax) {
     x[1] = Q.sg * x[1];
-    return quad_trig<SLOW>(__builtin_fma(Q.kap, x[0], x[1]), Q, mc, amax);
+    return quad_trig<SLOW>(quad_arg(x, Q), Q, mc, amax);
   }
   // One stage: x(s), v = trig(x(s)) -> x(s+1), v = trig(x(s+1)).  dtau1 = sg*dtau.
   template <bool SLOW>
@@ -314,7 +316,7 @@ struct PendulumDev {
     x[1] = __builtin_fma(dtau1, x[3], x[1]);
     x[2] = __builtin_fma(dtau, f2, x[2]);
     x[3] = __builtin_fma(dtau, f3, x[3]);
-    v = quad_trig<SLOW>(__builtin_fma(Q.kap, x[0], x[1]), Q, mc, amax);
+    v = quad_trig<SLOW>(quad_arg(x, Q), Q, mc, amax);
   }
   static __device__ __forceinline__ void ddHduu(T* m, const T*, const T* u, const T*, const T*) {  // :64-76
     m[0] = r0 + 2 * u[2];

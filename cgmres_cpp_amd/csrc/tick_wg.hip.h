@@ -247,130 +247,195 @@ struct WgCtx {
   // phase 1 writes x(s), trig(s) to `tab` — the LDS table S.R or, for the concurrent preamble sweeps, a per-workgroup
   // table in HBM — phase 2 reads `tab` and leaves the costate coefficients in S.R, phase 3 consumes S.R.
 
-  // phase 1: state sweep, cgmres.hpp:132-140, on the lanes [lane0, lane0 + 64) of one wave; x(dv) -> xT[c*IPW + i]
-  template <bool PERT>
+  // Workgroup barrier that orders LDS only.  __syncthreads() also drains the wave's outstanding HBM traffic
+  // (s_waitcnt vmcnt(0)); inside a sweep nothing another wave needs travels through HBM.
+  __device__ __forceinline__ void lds_barrier() const {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+  }
+  // Phases 1 and 2 are pipelined in chunks of stages (f_eval): the sweep wave publishes a chunk of the stage table
+  // and goes on with the next one while the other waves turn the published chunk into costate coefficients.
+  __device__ __forceinline__ int chunk_len() const { return 2 * ((P.dv + 9) / 10); }  // even: stages go in pairs
+
+  // phase 1: state sweep, cgmres.hpp:132-140, on the lanes [lane0, lane0 + 64) of one wave; x(dv) -> xT[c*IPW + i].
+  // PIPE: one lds_barrier() after every chunk (the caller's other waves run coeffs_chunked, which has the matching ones).
+  template <bool PERT, bool PIPE>
   __device__ __forceinline__ void sweep_state(int lane0, const T* x0c, T dtau, T* tab, T* xT, bool only_active) {
     constexpr int NX = M::NX, NU = M::NU, NC = M::NC;
-    const int dv = P.dv, lt = tid - lane0;
+    constexpr int STEP = NSTG * IPW;
+    const int dv = P.dv, lt = tid - lane0, CH = chunk_len();
     if (lt < 0 || lt >= 64) return;
     if constexpr (M::HAS_QUAD_SWEEP) {
-      // four lanes (one DPP quad) per instance — see PendulumDev::quad_trig / quad_advance
+      // four lanes (one DPP quad) per instance — see PendulumDev::quad_stage
       const int qi = lt >> 2, rho = lt & 3;
       const bool goq = lt < 4 * IPW && blockIdx.x * IPW + qi < P.B && (!only_active || S.flag[qi]);
+      typename M::QuadLane Q;
+      Q.init(rho, mc);
+      const T* __restrict__ U = S.U + qi * P.Lp;
+      const T* W = S.W + qi * P.Lp;
+      const T dtau1 = Q.sg * dtau;
+      T x[NX], v = T(0), amax = T(0);
       if (goq) {
-        typename M::QuadLane Q;
-        Q.init(rho, mc);
-        const T* __restrict__ U = S.U + qi * P.Lp;
-        const T* W = S.W + qi * P.Lp;
-        T x[NX];
-        // Branch-free stages, two per loop trip: all lanes store (see the slot map in models.hip.h), u0 of the next
-        // stage is fetched one stage ahead (index dv*NU is the pad word of the odd-pitch row), and every table
-        // pointer advances by the same constant so the second stage of a trip addresses with immediates.
-        auto sweep = [&](auto slow_tag) -> bool {
-          constexpr bool SLOW = decltype(slow_tag)::value;
-          constexpr int STEP = NSTG * IPW;
-          T amax = T(0);
 #pragma unroll
-          for (int c = 0; c < NX; ++c) x[c] = x0c[c * IPW + qi];
-          T v = M::template quad_begin<SLOW>(x, Q, mc, &amax);
-          T* pa = tab + qi;
-          T* pb = tab + qi + Q.slot_x1 * IPW;
-          T* pv = tab + qi + Q.slot_v * IPW;
-          const T* pu = U;
-          const T* pw = W;
-          const T dtau1 = Q.sg * dtau;
-          auto stage = [&](int o, T ur, T wr) {
-            T u0 = ur;
-            if (PERT) u0 = wr * P.h + u0;
-            pa[o * STEP + M::QSLOT_XA * IPW] = x[0];
-            pa[o * STEP + M::QSLOT_XB * IPW] = x[2];
-            pb[o * STEP] = x[1];
-            pv[o * STEP] = v;
-            M::template quad_stage<SLOW>(x, v, u0, dtau, dtau1, Q, mc, &amax);
-          };
-          T ua = pu[0], wa = PERT ? pw[0] : T(0);
-          int s = 0;
-          for (; s + 2 <= dv; s += 2) {
-            const T ub = pu[NU], wb = PERT ? pw[NU] : T(0);
-            stage(0, ua, wa);
-            ua = pu[2 * NU], wa = PERT ? pw[2 * NU] : T(0);
-            stage(1, ub, wb);
-            pa += 2 * STEP, pb += 2 * STEP, pv += 2 * STEP, pu += 2 * NU, pw += 2 * NU;
-          }
-          if (s < dv) stage(0, ua, wa);
-          return M::quad_arg_bad(amax);
+        for (int c = 0; c < NX; ++c) x[c] = x0c[c * IPW + qi];
+        v = M::template quad_begin<false>(x, Q, mc, &amax);
+      }
+      // Branch-free stages, two per loop trip: all lanes store (see the slot map in models.hip.h), u0 of the next
+      // stage is fetched one stage ahead (index dv*NU is the pad word of the odd-pitch row), and every table
+      // pointer advances by the same constant so the second stage of a trip addresses with immediates.
+      // table/control pointers and the prefetched u0 persist across chunks (only the slow redo rewinds them)
+      T* pa = tab + qi;
+      T* pb = pa + Q.slot_x1 * IPW;
+      T* pv = pa + Q.slot_v * IPW;
+      const T* pu = U;
+      const T* pw = W;
+      T ua = T(0), wa = T(0);
+      if (goq) ua = pu[0], wa = PERT ? pw[0] : T(0);
+      auto run = [&](auto slow_tag, int n) {
+        constexpr bool SLOW = decltype(slow_tag)::value;
+        auto stage = [&](int o, T ur, T wr) {
+          T u0 = ur;
+          if (PERT) u0 = wr * P.h + u0;
+          pa[o * STEP + M::QSLOT_XA * IPW] = x[0];
+          pa[o * STEP + M::QSLOT_XB * IPW] = x[2];
+          pb[o * STEP] = x[1];
+          pv[o * STEP] = v;
+          M::template quad_stage<SLOW>(x, v, u0, dtau, dtau1, Q, mc, &amax);
         };
-        if (__builtin_expect(__any(sweep(std::false_type{})), 0)) sweep(std::true_type{});
-        if (rho == M::QLANE_TRUE_X) {
-#pragma unroll
-          for (int c = 0; c < NX; ++c) xT[c * IPW + qi] = x[c];
+        int k = 0;
+        for (; k + 2 <= n; k += 2) {
+          const T ub = pu[NU], wb = PERT ? pw[NU] : T(0);
+          stage(0, ua, wa);
+          ua = pu[2 * NU], wa = PERT ? pw[2 * NU] : T(0);
+          stage(1, ub, wb);
+          pa += 2 * STEP, pb += 2 * STEP, pv += 2 * STEP, pu += 2 * NU, pw += 2 * NU;
         }
+        if (k < n) {  // odd tail: only the last chunk can have one
+          stage(0, ua, wa);
+          pa += STEP, pb += STEP, pv += STEP, pu += NU, pw += NU;
+        }
+      };
+      for (int s0 = 0; s0 < dv; s0 += CH) {
+        const int n = dv - s0 < CH ? dv - s0 : CH;
+        if (goq) {
+          T xs[NX];
+#pragma unroll
+          for (int c = 0; c < NX; ++c) xs[c] = x[c];
+          run(std::false_type{}, n);
+          // an argument outside the fast range of the trig kernel: redo this chunk with the library sin/cos
+          if (__builtin_expect(__any(M::quad_arg_bad(amax)), 0)) {
+#pragma unroll
+            for (int c = 0; c < NX; ++c) x[c] = xs[c];
+            pa = tab + qi + s0 * STEP, pb = pa + Q.slot_x1 * IPW, pv = pa + Q.slot_v * IPW;
+            pu = U + s0 * NU, pw = W + s0 * NU;
+            ua = pu[0], wa = PERT ? pw[0] : T(0);
+            v = M::template quad_trig<true>(M::quad_arg(x, Q), Q, mc, &amax);
+            run(std::true_type{}, n);
+            if (n & 1) ua = pu[0], wa = PERT ? pw[0] : T(0);
+            amax = T(0);
+          }
+        }
+        if (PIPE) lds_barrier();
+      }
+      if (goq && rho == M::QLANE_TRUE_X) {
+#pragma unroll
+        for (int c = 0; c < NX; ++c) xT[c * IPW + qi] = x[c];
       }
     } else {
       const int i = lt;
-      if (i < IPW && blockIdx.x * IPW + i < P.B && (!only_active || S.flag[i])) {
-        const T* __restrict__ U = S.U + i * P.Lp;
-        const T* W = S.W + i * P.Lp;
-        T* __restrict__ R = tab + i;
-        T xs[NX];
+      const bool go = i < IPW && blockIdx.x * IPW + i < P.B && (!only_active || S.flag[i]);
+      const T* __restrict__ U = S.U + i * P.Lp;
+      const T* W = S.W + i * P.Lp;
+      T* __restrict__ R = tab + i;
+      T xs[NX];
+      if (go) {
 #pragma unroll
         for (int c = 0; c < NX; ++c) xs[c] = x0c[c * IPW + i];
-        for (int s = 0; s < dv; ++s) {
-          T u[M::NU_DYN], f[NX], tr[NC > 0 ? NC : 1];
+      }
+      for (int s0 = 0; s0 < dv; s0 += CH) {
+        const int s1 = s0 + CH < dv ? s0 + CH : dv;
+        if (go) {
+          for (int s = s0; s < s1; ++s) {
+            T u[M::NU_DYN], f[NX], tr[NC > 0 ? NC : 1];
 #pragma unroll
-          for (int j = 0; j < M::NU_DYN; ++j) {
-            T uj = U[s * NU + j];
-            if (PERT) uj = W[s * NU + j] * P.h + uj;
-            u[j] = uj;
+            for (int j = 0; j < M::NU_DYN; ++j) {
+              T uj = U[s * NU + j];
+              if (PERT) uj = W[s * NU + j] * P.h + uj;
+              u[j] = uj;
+            }
+#pragma unroll
+            for (int c = 0; c < NX; ++c) R[(s * NSTG + c) * IPW] = xs[c];
+            M::dxdt(f, xs, u, tr, mc);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) R[(s * NSTG + NX + c) * IPW] = tr[c];
+#pragma unroll
+            for (int c = 0; c < NX; ++c) xs[c] = f[c] * dtau + xs[c];
           }
-#pragma unroll
-          for (int c = 0; c < NX; ++c) R[(s * NSTG + c) * IPW] = xs[c];
-          M::dxdt(f, xs, u, tr, mc);
-#pragma unroll
-          for (int c = 0; c < NC; ++c) R[(s * NSTG + NX + c) * IPW] = tr[c];
-#pragma unroll
-          for (int c = 0; c < NX; ++c) xs[c] = f[c] * dtau + xs[c];
         }
+        if (PIPE) lds_barrier();
+      }
+      if (go) {
 #pragma unroll
         for (int c = 0; c < NX; ++c) xT[c * IPW + i] = xs[c];
       }
     }
   }
 
-  // phase 2: costate-free part of every backward stage, all threads, items (s, i) with i fastest.
+  // phase 2: costate-free part of one backward stage of one instance.
   // Reads x/trig from `tab`, writes the coefficients to S.R and the costate-free part of the result to `out`.
   template <bool PERT, int MODE>
-  __device__ __forceinline__ void sweep_coeffs(T dtau, const T* tab, T* out, bool only_active) {
+  __device__ __forceinline__ void coeff_item(int s, int i, T dtau, const T* tab, T* out) {
     constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC, NBW = M::NBW;
-    const int dv = P.dv;
     const T sc_phi = MODE == F_RHS ? P.one_m_zh : T(1.0);
-    for (int q = tid; q < dv * IPW; q += IPW * 16) {
+    T x[NX], tr[NC > 0 ? NC : 1], u[NU], p[NP > 0 ? NP : 1], bw[NBW], phi[NU];
+    const T* Rs = tab + (s * NSTG) * IPW + i;
+    T* Rd = S.R + (s * NSTG) * IPW + i;
+#pragma unroll
+    for (int c = 0; c < NX; ++c) x[c] = Rs[c * IPW];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) tr[c] = Rs[(NX + c) * IPW];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+      T uj = S.U[i * P.Lp + s * NU + j];
+      if (PERT) uj = S.W[i * P.Lp + s * NU + j] * P.h + uj;
+      u[j] = uj;
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) p[j] = S.p[i * P.Pp + s * NP + j];
+    M::stage_coeffs(bw, phi, x, u, p, tr, dtau);
+#pragma unroll
+    for (int c = 0; c < NBW; ++c) Rd[c * IPW] = bw[c];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+      T rj = phi[j];
+      if (MODE != F_PLAIN) rj = (rj * sc_phi - S.Fh[i * P.Lp + s * NU + j]) * P.inv_h;
+      out[i * P.Lp + s * NU + j] = rj;
+    }
+  }
+  // all threads, items (s, i) with i fastest
+  template <bool PERT, int MODE>
+  __device__ __forceinline__ void sweep_coeffs(T dtau, const T* tab, T* out, bool only_active) {
+    for (int q = tid; q < P.dv * IPW; q += IPW * 16) {
       const int i = q & (IPW - 1), s = q / IPW;
       if (blockIdx.x * IPW + i >= P.B) continue;
       if (only_active && !S.flag[i]) continue;
-      T x[NX], tr[NC > 0 ? NC : 1], u[NU], p[NP > 0 ? NP : 1], bw[NBW], phi[NU];
-      const T* Rs = tab + (s * NSTG) * IPW + i;
-      T* Rd = S.R + (s * NSTG) * IPW + i;
-#pragma unroll
-      for (int c = 0; c < NX; ++c) x[c] = Rs[c * IPW];
-#pragma unroll
-      for (int c = 0; c < NC; ++c) tr[c] = Rs[(NX + c) * IPW];
-#pragma unroll
-      for (int j = 0; j < NU; ++j) {
-        T uj = S.U[i * P.Lp + s * NU + j];
-        if (PERT) uj = S.W[i * P.Lp + s * NU + j] * P.h + uj;
-        u[j] = uj;
-      }
-#pragma unroll
-      for (int j = 0; j < NP; ++j) p[j] = S.p[i * P.Pp + s * NP + j];
-      M::stage_coeffs(bw, phi, x, u, p, tr, dtau);
-#pragma unroll
-      for (int c = 0; c < NBW; ++c) Rd[c * IPW] = bw[c];
-#pragma unroll
-      for (int j = 0; j < NU; ++j) {
-        T rj = phi[j];
-        if (MODE != F_PLAIN) rj = (rj * sc_phi - S.Fh[i * P.Lp + s * NU + j]) * P.inv_h;
-        out[i * P.Lp + s * NU + j] = rj;
+      coeff_item<PERT, MODE>(s, i, dtau, tab, out);
+    }
+  }
+  // the waves other than wave 0, chunk by chunk behind sweep_state<PERT, true> (one lds_barrier() before every chunk)
+  template <bool PERT, int MODE>
+  __device__ __forceinline__ void coeffs_chunked(T dtau, T* out, bool only_active) {
+    constexpr int NL = IPW * 16 - 64;
+    const int dv = P.dv, CH = chunk_len(), lt = tid - 64;
+    for (int s0 = 0; s0 < dv; s0 += CH) {
+      const int n = dv - s0 < CH ? dv - s0 : CH;
+      lds_barrier();
+      for (int q = lt; q < n * IPW; q += NL) {
+        const int i = q & (IPW - 1), s = s0 + q / IPW;
+        if (blockIdx.x * IPW + i >= P.B) continue;
+        if (only_active && !S.flag[i]) continue;
+        coeff_item<PERT, MODE>(s, i, dtau, S.R, out);
       }
     }
   }
@@ -428,11 +493,20 @@ struct WgCtx {
   // inside); the caller adds the barrier that publishes `out`.  x0c = initial state, component-major LDS [c*IPW + i].
   template <bool PERT, int MODE>
   __device__ __forceinline__ void f_eval(const T* x0c, T dtau, T* out, bool only_active) {
-    sweep_state<PERT>(0, x0c, dtau, S.R, S.xT, only_active);
-    __syncthreads();
-    CGM_STAMP(*this, 4);
-    sweep_coeffs<PERT, MODE>(dtau, S.R, out, only_active);
-    __syncthreads();
+    if constexpr (IPW * 16 >= 128) {
+      if (tid < 64)
+        sweep_state<PERT, true>(0, x0c, dtau, S.R, S.xT, only_active);
+      else
+        coeffs_chunked<PERT, MODE>(dtau, out, only_active);
+      CGM_STAMP(*this, 4);
+      __syncthreads();
+    } else {
+      sweep_state<PERT, false>(0, x0c, dtau, S.R, S.xT, only_active);
+      __syncthreads();
+      CGM_STAMP(*this, 4);
+      sweep_coeffs<PERT, MODE>(dtau, S.R, out, only_active);
+      __syncthreads();
+    }
     CGM_STAMP(*this, 5);
     sweep_costate<MODE>(dtau, S.xT, out, only_active);
   }
@@ -468,9 +542,9 @@ struct WgCtx {
       T* tab0 = P.scr + size_t(blockIdx.x) * 2 * tab_n;
       T* tab1 = tab0 + tab_n;
       T* xT0 = S.xT, *xT1 = S.xT + M::NX * IPW, *xT2 = S.xT + 2 * M::NX * IPW;
-      sweep_state<false>(0, S.xh, P.dtau_h, S.R, xT0, false);
-      sweep_state<false>(64, S.xs, P.dtau_0, tab0, xT1, false);
-      if (WITH_AX0) sweep_state<true>(128, S.xh, P.dtau_h, tab1, xT2, false);
+      sweep_state<false, false>(0, S.xh, P.dtau_h, S.R, xT0, false);
+      sweep_state<false, false>(64, S.xs, P.dtau_0, tab0, xT1, false);
+      if (WITH_AX0) sweep_state<true, false>(128, S.xh, P.dtau_h, tab1, xT2, false);
       __threadfence_block();
       __syncthreads();  // drains vmcnt: the HBM tables are complete and visible to the other waves of this CU
       CGM_STAMP(*this, 4);
