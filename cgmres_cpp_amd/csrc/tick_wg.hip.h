@@ -256,7 +256,9 @@ struct WgCtx {
   }
   // Phases 1 and 2 are pipelined in chunks of stages (f_eval): the sweep wave publishes a chunk of the stage table
   // and goes on with the next one while the other waves turn the published chunk into costate coefficients.
-  __device__ __forceinline__ int chunk_len() const { return 2 * ((P.dv + 9) / 10); }  // even: stages go in pairs
+  // Four chunks measured best at dv = 50 (14+14+14+8): a barrier costs the sweep wave ~300 cycles, and only the
+  // processing of the last chunk stays on the critical path.
+  __device__ __forceinline__ int chunk_len() const { return 2 * ((P.dv + 7) / 8); }  // even: stages go in pairs
 
   // phase 1: state sweep, cgmres.hpp:132-140, on the lanes [lane0, lane0 + 64) of one wave; x(dv) -> xT[c*IPW + i].
   // PIPE: one lds_barrier() after every chunk (the caller's other waves run coeffs_chunked, which has the matching ones).
@@ -311,7 +313,7 @@ struct WgCtx {
           stage(1, ub, wb);
           pa += 2 * STEP, pb += 2 * STEP, pv += 2 * STEP, pu += 2 * NU, pw += 2 * NU;
         }
-        if (k < n) {  // odd tail: only the last chunk can have one
+        if (k < n) {  // odd tail: only the last chunk can have one (chunk_len() is even)
           stage(0, ua, wa);
           pa += STEP, pb += STEP, pv += STEP, pu += NU, pw += NU;
         }

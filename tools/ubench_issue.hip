@@ -11,6 +11,7 @@ template <int TEST>
 __global__ void k(double* out, long long* cyc, int iters, double b, double c) {
   double a = threadIdx.x * 1e-3 + 1.0, d = threadIdx.x * 2e-3 + 1.5, e = a + 3, f = d + 4;
   int i0 = threadIdx.x, i1 = threadIdx.x * 3;
+  double2 i128 = {0, 0};
   __shared__ double lds[1024];
   lds[threadIdx.x] = a;
   __syncthreads();
@@ -50,10 +51,23 @@ __global__ void k(double* out, long long* cyc, int iters, double b, double c) {
     if (TEST == 23) asm volatile(REPT(64, "v_accvgpr_read_b32 %0, a0") : "+v"(i0));
     if (TEST == 24) asm volatile(REPT(64, "s_add_u32 s20, s20, 1") : : : "s20", "scc");
     if (TEST == 25) asm volatile(REPT(64, "v_readlane_b32 s20, %0, 3") : : "v"(i0) : "s20");
+    // LDS stores with one active lane per quad (exec = 0x1111...) / 16 contiguous active lanes
+    if (TEST == 26)
+      asm volatile("s_mov_b64 s[20:21], exec\n s_mov_b32 s22, 0x11111111\n s_mov_b32 s23, 0x11111111\n s_mov_b64 exec, s[22:23]\n"
+                   REPT(64, "ds_write_b64 %1, %0") "s_mov_b64 exec, s[20:21]" : : "v"(a), "v"(addr) : "memory", "s20", "s21", "s22", "s23");
+    if (TEST == 27)
+      asm volatile("s_mov_b64 s[20:21], exec\n s_mov_b32 s22, 0x11111111\n s_mov_b32 s23, 0x11111111\n s_mov_b64 exec, s[22:23]\n"
+                   REPT(64, "ds_write2_b64 %1, %0, %0 offset1:16") "s_mov_b64 exec, s[20:21]" : : "v"(a), "v"(addr) : "memory", "s20", "s21", "s22", "s23");
+    if (TEST == 28)
+      asm volatile("s_mov_b64 s[20:21], exec\n s_mov_b64 exec, 0xffff\n"
+                   REPT(64, "ds_write2_b64 %1, %0, %0 offset1:16") "s_mov_b64 exec, s[20:21]" : : "v"(a), "v"(addr) : "memory", "s20", "s21");
+    if (TEST == 29) asm volatile(REPT(64, "ds_read2_b64 %0, %1 offset1:16") : "=v"(i128) : "v"(addr) : "memory");
+    if (TEST == 30) asm volatile(REPT(64, "ds_read_b64 %0, %1") : "=v"(a) : "v"(addr) : "memory");
   }
   long long t1 = __builtin_readcyclecounter();
   if (TEST == 14 || TEST == 15) __syncthreads();
-  out[blockIdx.x * blockDim.x + threadIdx.x] = a + d + e + f + i0 + i1 + lds[(threadIdx.x * 7) & 1023];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  out[blockIdx.x * blockDim.x + threadIdx.x] = i128.x + a + d + e + f + i0 + i1 + lds[(threadIdx.x * 7) & 1023];
   if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
 }
 
@@ -100,5 +114,10 @@ int main() {
   run<13>("ds_read_b64 + wait (LDS latency)", 64);
   run<14>("ds_write_b64 64 lanes, 4 lanes/address", 64);
   run<15>("ds_write2_b64 64 lanes, 4 lanes/address", 64);
+  run<26>("ds_write_b64 one lane per quad (16 active)", 64);
+  run<27>("ds_write2_b64 one lane per quad (16 active)", 64);
+  run<28>("ds_write2_b64 lanes 0-15 active", 64);
+  run<29>("ds_read2_b64 back to back (no wait)", 64);
+  run<30>("ds_read_b64 back to back (no wait)", 64);
   return 0;
 }
