@@ -170,6 +170,18 @@ struct WgCtx {
       if (e < P.L) lds[inst * P.Lp + e] = reg[m];
     }
   }
+  // The direction d of a matrix-vector product is published to the sweeps as the perturbed control U + h*d
+  // (cgmres.hpp:166-168 forms it in every stage); the sweep phases then read one array instead of two.
+  __device__ __forceinline__ void publish_direction(const T* reg) const {
+    T uu[MAXM];  // all reads first (pad lanes read in-bounds words of the next row, never stored)
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) uu[m] = S.U[inst * P.Lp + elem(m)];
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+      const int e = elem(m);
+      if (e < P.L) S.W[inst * P.Lp + e] = reg[m] * P.h + uu[m];
+    }
+  }
   __device__ __forceinline__ void reg_to_row(T* g, size_t pitch, const T* reg) const {
     if (!valid) return;
 #pragma unroll
@@ -274,8 +286,7 @@ struct WgCtx {
       const bool goq = lt < 4 * IPW && blockIdx.x * IPW + qi < P.B && (!only_active || S.flag[qi]);
       typename M::QuadLane Q;
       Q.init(rho, mc);
-      const T* __restrict__ U = S.U + qi * P.Lp;
-      const T* W = S.W + qi * P.Lp;
+      const T* __restrict__ U = (PERT ? S.W : S.U) + qi * P.Lp;  // PERT: W holds U + h*direction (publish_direction)
       const T dtau1 = Q.sg * dtau;
       T x[NX], v = T(0), amax = T(0);
       if (goq) {
@@ -291,14 +302,11 @@ struct WgCtx {
       T* pb = pa + Q.slot_x1 * IPW;
       T* pv = pa + Q.slot_v * IPW;
       const T* pu = U;
-      const T* pw = W;
-      T ua = T(0), wa = T(0);
-      if (goq) ua = pu[0], wa = PERT ? pw[0] : T(0);
+      T ua = T(0);
+      if (goq) ua = pu[0];
       auto run = [&](auto slow_tag, int n) {
         constexpr bool SLOW = decltype(slow_tag)::value;
-        auto stage = [&](int o, T ur, T wr) {
-          T u0 = ur;
-          if (PERT) u0 = wr * P.h + u0;
+        auto stage = [&](int o, T u0) {
           pa[o * STEP + M::QSLOT_XA * IPW] = x[0];
           pa[o * STEP + M::QSLOT_XB * IPW] = x[2];
           pb[o * STEP] = x[1];
@@ -307,15 +315,15 @@ struct WgCtx {
         };
         int k = 0;
         for (; k + 2 <= n; k += 2) {
-          const T ub = pu[NU], wb = PERT ? pw[NU] : T(0);
-          stage(0, ua, wa);
-          ua = pu[2 * NU], wa = PERT ? pw[2 * NU] : T(0);
-          stage(1, ub, wb);
-          pa += 2 * STEP, pb += 2 * STEP, pv += 2 * STEP, pu += 2 * NU, pw += 2 * NU;
+          const T ub = pu[NU];
+          stage(0, ua);
+          ua = pu[2 * NU];
+          stage(1, ub);
+          pa += 2 * STEP, pb += 2 * STEP, pv += 2 * STEP, pu += 2 * NU;
         }
         if (k < n) {  // odd tail: only the last chunk can have one (chunk_len() is even)
-          stage(0, ua, wa);
-          pa += STEP, pb += STEP, pv += STEP, pu += NU, pw += NU;
+          stage(0, ua);
+          pa += STEP, pb += STEP, pv += STEP, pu += NU;
         }
       };
       for (int s0 = 0; s0 < dv; s0 += CH) {
@@ -330,11 +338,11 @@ struct WgCtx {
 #pragma unroll
             for (int c = 0; c < NX; ++c) x[c] = xs[c];
             pa = tab + qi + s0 * STEP, pb = pa + Q.slot_x1 * IPW, pv = pa + Q.slot_v * IPW;
-            pu = U + s0 * NU, pw = W + s0 * NU;
-            ua = pu[0], wa = PERT ? pw[0] : T(0);
+            pu = U + s0 * NU;
+            ua = pu[0];
             v = M::template quad_trig<true>(M::quad_arg(x, Q), Q, mc, &amax);
             run(std::true_type{}, n);
-            if (n & 1) ua = pu[0], wa = PERT ? pw[0] : T(0);
+            if (n & 1) ua = pu[0];
             amax = T(0);
           }
         }
@@ -347,8 +355,7 @@ struct WgCtx {
     } else {
       const int i = lt;
       const bool go = i < IPW && blockIdx.x * IPW + i < P.B && (!only_active || S.flag[i]);
-      const T* __restrict__ U = S.U + i * P.Lp;
-      const T* W = S.W + i * P.Lp;
+      const T* __restrict__ U = (PERT ? S.W : S.U) + i * P.Lp;
       T* __restrict__ R = tab + i;
       T xs[NX];
       if (go) {
@@ -361,11 +368,7 @@ struct WgCtx {
           for (int s = s0; s < s1; ++s) {
             T u[M::NU_DYN], f[NX], tr[NC > 0 ? NC : 1];
 #pragma unroll
-            for (int j = 0; j < M::NU_DYN; ++j) {
-              T uj = U[s * NU + j];
-              if (PERT) uj = W[s * NU + j] * P.h + uj;
-              u[j] = uj;
-            }
+            for (int j = 0; j < M::NU_DYN; ++j) u[j] = U[s * NU + j];
 #pragma unroll
             for (int c = 0; c < NX; ++c) R[(s * NSTG + c) * IPW] = xs[c];
             M::dxdt(f, xs, u, tr, mc);
@@ -398,11 +401,7 @@ struct WgCtx {
 #pragma unroll
     for (int c = 0; c < NC; ++c) tr[c] = Rs[(NX + c) * IPW];
 #pragma unroll
-    for (int j = 0; j < NU; ++j) {
-      T uj = S.U[i * P.Lp + s * NU + j];
-      if (PERT) uj = S.W[i * P.Lp + s * NU + j] * P.h + uj;
-      u[j] = uj;
-    }
+    for (int j = 0; j < NU; ++j) u[j] = (PERT ? S.W : S.U)[i * P.Lp + s * NU + j];
 #pragma unroll
     for (int j = 0; j < NP; ++j) p[j] = S.p[i * P.Pp + s * NP + j];
     M::stage_coeffs(bw, phi, x, u, p, tr, dtau);
@@ -634,7 +633,7 @@ struct WgCtx {
 #pragma unroll
         for (int m = 0; m < MAXM; ++m) vcur[m] = vcur[m] * inv;
         store_vec(vrow(0), vcur);
-        reg_to_lds(S.W, vcur);
+        publish_direction(vcur);
       }
       if (r == 0) S.flag[inst] = active ? 1 : 0;
     }
@@ -726,7 +725,7 @@ struct WgCtx {
 #pragma unroll
           for (int m = 0; m < MAXM; ++m) vcur[m] = w[m] * inv;
           store_vec(vrow(k + 1), vcur);
-          reg_to_lds(S.W, vcur);
+          publish_direction(vcur);
           // Hessenberg column k: stored reflectors, new reflector, residual rotation (:71-90) — scalar work.
           // Every lane of the row computes it from the same LDS words (broadcast reads; a row never straddles
           // a wave, and LDS operations of one wave complete in order), lane 0 writes back: the convergence
@@ -858,7 +857,7 @@ __global__ __launch_bounds__(IPW * 16) __attribute__((amdgpu_waves_per_eu(1, 1))
   for (int q = C.r; q < P.Hp; q += 16) C.S.H[C.inst * P.Hp + q] = T(0);
   __syncthreads();
   CGM_STAMP(C, 0);
-  C.reg_to_lds(C.S.W, du);  // direction of the first mat-vec: x0 = dUdt (warm start, cgmres.hpp:99)
+  C.publish_direction(du);  // direction of the first mat-vec: x0 = dUdt (warm start, cgmres.hpp:99)
   T ax0[MAXM];
   C.template preamble<true>(bb, ax0);  // Fh in LDS; b and A*dUdt in registers
   CGM_STAMP(C, 1);
@@ -949,7 +948,7 @@ __global__ __launch_bounds__(IPW * 16) __attribute__((amdgpu_waves_per_eu(1, 1))
   if (C.valid && C.r < M::NX) C.S.xh[C.r * IPW + C.inst] = P.xdxh[size_t(C.b) * M::NX + C.r];
   for (int q = C.r; q < P.Hp; q += 16) C.S.H[C.inst * P.Hp + q] = T(0);
   load_im(a, P.hook_in0);
-  C.reg_to_lds(C.S.W, a);
+  C.publish_direction(a);
   __syncthreads();
   C.ax(false);
   if (P.mode == WG_HOOK_AX) {

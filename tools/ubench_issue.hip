@@ -11,11 +11,12 @@ template <int TEST>
 __global__ void k(double* out, long long* cyc, int iters, double b, double c) {
   double a = threadIdx.x * 1e-3 + 1.0, d = threadIdx.x * 2e-3 + 1.5, e = a + 3, f = d + 4;
   int i0 = threadIdx.x, i1 = threadIdx.x * 3;
-  double2 i128 = {0, 0};
-  __shared__ double lds[1024];
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  v4i i128 = {0, 0, 0, 0};
+  __shared__ double lds[2048];
   lds[threadIdx.x] = a;
   __syncthreads();
-  int addr = (threadIdx.x >> 2) * 8;
+  int addr = (threadIdx.x >> 2) * 8, addr2 = threadIdx.x * 8, addr3 = threadIdx.x * 16;
   long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
     if (TEST == 0) asm volatile(REPT(64, "v_fma_f64 %0, %0, %1, %2") : "+v"(a) : "v"(b), "v"(c));
@@ -61,13 +62,19 @@ __global__ void k(double* out, long long* cyc, int iters, double b, double c) {
     if (TEST == 28)
       asm volatile("s_mov_b64 s[20:21], exec\n s_mov_b64 exec, 0xffff\n"
                    REPT(64, "ds_write2_b64 %1, %0, %0 offset1:16") "s_mov_b64 exec, s[20:21]" : : "v"(a), "v"(addr) : "memory", "s20", "s21");
+    if (TEST == 31) asm volatile(REPT(64, "ds_write_b64 %1, %0") : : "v"(a), "v"(addr2) : "memory");
+    if (TEST == 32) asm volatile(REPT(64, "ds_write_b32 %1, %0") : : "v"(i0), "v"(addr2) : "memory");
+    if (TEST == 33) asm volatile(REPT(64, "ds_write_b128 %1, %0") : : "v"(i128), "v"(addr3) : "memory");
+    if (TEST == 34) asm volatile(REPT(64, "ds_write2_b64 %1, %0, %0 offset1:16") : : "v"(a), "v"(addr2) : "memory");
+    if (TEST == 35) asm volatile(REPT(64, "ds_read_b128 %0, %1") : "=v"(i128) : "v"(addr3) : "memory");
+    if (TEST == 36) asm volatile(REPT(32, "ds_write_b64 %1, %0\n v_fma_f64 %2, %2, %3, %4\n v_fma_f64 %2, %2, %3, %4\n v_fma_f64 %2, %2, %3, %4") : : "v"(a), "v"(addr2), "v"(d), "v"(b), "v"(c) : "memory");
     if (TEST == 29) asm volatile(REPT(64, "ds_read2_b64 %0, %1 offset1:16") : "=v"(i128) : "v"(addr) : "memory");
     if (TEST == 30) asm volatile(REPT(64, "ds_read_b64 %0, %1") : "=v"(a) : "v"(addr) : "memory");
   }
   long long t1 = __builtin_readcyclecounter();
   if (TEST == 14 || TEST == 15) __syncthreads();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  out[blockIdx.x * blockDim.x + threadIdx.x] = i128.x + a + d + e + f + i0 + i1 + lds[(threadIdx.x * 7) & 1023];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = i128[0] + a + d + e + f + i0 + i1 + lds[(threadIdx.x * 7) & 1023];
   if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
 }
 
@@ -117,6 +124,12 @@ int main() {
   run<26>("ds_write_b64 one lane per quad (16 active)", 64);
   run<27>("ds_write2_b64 one lane per quad (16 active)", 64);
   run<28>("ds_write2_b64 lanes 0-15 active", 64);
+  run<31>("ds_write_b64 lane-contiguous", 64);
+  run<32>("ds_write_b32 lane-contiguous", 64);
+  run<33>("ds_write_b128 lane-contiguous", 64);
+  run<34>("ds_write2_b64 lane-contiguous", 64);
+  run<35>("ds_read_b128 lane-contiguous (no wait)", 64);
+  run<36>("ds_write_b64 + 3 v_fma_f64 (per 4 instr)", 128);
   run<29>("ds_read2_b64 back to back (no wait)", 64);
   run<30>("ds_read_b64 back to back (no wait)", 64);
   return 0;
