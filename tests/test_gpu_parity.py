@@ -180,6 +180,44 @@ def test_seeded_batch_vs_oracle(orc, model, dv, kmax, tol, B, ticks, variant):
     c.close()
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_large_angles_take_the_library_trig_path(orc, variant):
+    """Angles beyond the fast range of the device trig kernel (|arg| >= 1e5) make the wg sweep redo the affected
+    chunk of stages with the library sin/cos.  A batch that mixes such instances with ordinary ones (same
+    workgroup, so the redo also covers the ordinary ones) must still match the oracle instance by instance."""
+    model, dv, kmax, tol, B = 0, 50, 10, 1e-6, 24
+    x0, u0, p = orc.batch_scenario(model, B)
+    two_pi = 2.0 * np.pi
+    x0[1, 0] += 20000 * two_pi   # x0 - x1 out of range from the first stage on
+    x0[5, 1] -= 30000 * two_pi   # both angles out of range
+    x0[17, 0] += 15915 * two_pi  # just below 1e5: crosses the cut-over only if the sweep moves it
+    x0[17, 1] += 15915 * two_pi
+    c = cg.CgmresBatch(model, batch=B, dv=dv, k_max=kmax, tol=tol, variant=variant)
+    c.set_ptau_repeat(p)
+    c.init_u0(u0)
+    c.init_u0_newton(u0, x0, p, 10)
+    refs = _oracle_batch(orc, model, dv, kmax, tol, x0, u0, p)
+    x = x0.copy()
+    for tick in range(3):
+        t_o, U_o, d_o = zip(*[r.get_state() for r in refs])
+        c.set_state(t_o[0], np.array(U_o), np.array(d_o))
+        u = c.control(x)
+        assert np.all(np.isfinite(u))
+        _, U1, d1 = c.get_state()
+        for i, r in enumerate(refs):
+            ur = r.control(x[i])
+            if i in (1, 5, 17):
+                # |angle| ~ 1e5 has an absolute resolution of 1.5e-11 rad and these instances sit ~1e5 rad from
+                # their target (|u| ~ 1e3): compare at 1e-7 relative — the point is that the library path is
+                # taken and agrees, not the conditioning of an absurd scenario
+                assert np.max(np.abs(u[i] - ur)) <= 1e-7 * max(1.0, np.max(np.abs(ur))), (tick, i, u[i], ur)
+            else:
+                assert np.max(np.abs(u[i] - ur)) <= U_TOL, (tick, i, u[i], ur)
+                assert dudt_close(d1[i], r.get_state()[2]), (tick, i)
+            x[i] = x[i] + r.plant(x[i], ur) * r.dt
+    c.close()
+
+
 def test_closed_loop_device_matches_host_loop(orc):
     """closed_loop_device (plant on the GPU, device pointers) == host-driven loop with the same plant rule."""
     B, dv, km, n = 70, 50, 10, 8
