@@ -395,7 +395,6 @@ struct WgCtx {
     const T sc_phi = MODE == F_RHS ? P.one_m_zh : T(1.0);
     T x[NX], tr[NC > 0 ? NC : 1], u[NU], p[NP > 0 ? NP : 1], bw[NBW], phi[NU];
     const T* Rs = tab + (s * NSTG) * IPW + i;
-    T* Rd = S.R + (s * NSTG) * IPW + i;
 #pragma unroll
     for (int c = 0; c < NX; ++c) x[c] = Rs[c * IPW];
 #pragma unroll
@@ -405,8 +404,16 @@ struct WgCtx {
 #pragma unroll
     for (int j = 0; j < NP; ++j) p[j] = S.p[i * P.Pp + s * NP + j];
     M::stage_coeffs(bw, phi, x, u, p, tr, dtau);
+    // coefficients go back pair-interleaved — pair c of instance i at [(c*IPW + i)*2, +1] of the stage's region —
+    // so the costate sweep fetches them with 16-byte LDS reads (ds_read_b128: 8 cycles; ds_read2_b64: 16).  In place
+    // is safe: the 16 instances of a stage are 16 adjacent lanes of ONE wave in ONE pass, and all their reads of
+    // x/trig precede these writes in program order.
+    static_assert(NBW % 2 == 0 && (IPW * 16) % 64 == 0, "pair-interleaved costate coefficients");
+    {
+      Pair* Rp = reinterpret_cast<Pair*>(S.R + (s * NSTG) * IPW) + i;
 #pragma unroll
-    for (int c = 0; c < NBW; ++c) Rd[c * IPW] = bw[c];
+      for (int c = 0; c < NBW; c += 2) Rp[(c / 2) * IPW] = Pair{bw[c], bw[c + 1]};
+    }
 #pragma unroll
     for (int j = 0; j < NU; ++j) {
       T rj = phi[j];
@@ -464,8 +471,12 @@ struct WgCtx {
       T bw[NBW], o[NUL];
     };
     auto fetch = [&](Ops& a, const T* pr, const T* po) {
+      const Pair* pp = reinterpret_cast<const Pair*>(pr);
 #pragma unroll
-      for (int c = 0; c < NBW; ++c) a.bw[c] = pr[c * IPW];
+      for (int c = 0; c < NBW; c += 2) {
+        const Pair t = pp[(c / 2) * IPW];
+        a.bw[c] = t.a, a.bw[c + 1] = t.b;
+      }
 #pragma unroll
       for (int j = 0; j < NUL; ++j) a.o[j] = po[j];
     };
@@ -477,7 +488,7 @@ struct WgCtx {
     };
     Ops A, B;
     int s = dv - 1;
-    const T* pr = S.R + i + (dv - 2) * STEP;  // the lower stage of the current pair
+    const T* pr = S.R + 2 * i + (dv - 2) * STEP;  // the lower stage of the current pair (pair-interleaved, see coeff_item)
     T* po = out + i * P.Lp + (dv - 2) * NU;
     fetch(A, pr + STEP, po + NU);
     for (; s >= 1; s -= 2) {
