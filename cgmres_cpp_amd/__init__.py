@@ -23,7 +23,8 @@ ABI_VERSION = 1
 
 # every symbol include/cgmres_hip.h declares (tests/test_capi_symbols.py checks header == this == library)
 SYMBOLS = [
-    "cgmres_hip_model_info", "cgmres_hip_default_config", "cgmres_hip_model_probe", "cgmres_hip_selftest_sincos",
+    "cgmres_hip_model_info", "cgmres_hip_default_config", "cgmres_hip_model_probe", "cgmres_hip_register_model",
+    "cgmres_hip_selftest_sincos",
     "cgmres_hip_last_error",
     "cgmres_hip_device_count", "cgmres_hip_create", "cgmres_hip_destroy", "cgmres_hip_get_config",
     "cgmres_hip_set_ptau", "cgmres_hip_set_ptau_repeat", "cgmres_hip_init_u0", "cgmres_hip_init_u0_newton",

@@ -6,6 +6,10 @@
 //                                      reductions — the default whenever the problem fits its LDS budget
 //   variant 1 "lane" (tick_lane.hip.h) one lane per instance, reference statement order, any size
 // There is no CPU implementation of the path in this library.
+#include <dlfcn.h>
+
+#include <mutex>
+
 #include "ctx_common.hip.h"
 #include "factory.hip.h"
 #include "util_kernels.hip.h"
@@ -14,8 +18,32 @@ namespace {
 
 using cgm::fail;
 
+// User models registered at run time (cgmres_hip_register_model): model ids CGMRES_HIP_MODEL_USER_BASE + n.
+struct Plugin {
+  void* dl;
+  std::string path;
+  cgm::ModelInfo info;
+  cgmres_hip_ctx* (*make)(const cgmres_hip_config*);
+  int (*probe)(const double*, const double*, const double*, const double*, double*, void*);
+  const char* (*last_error)(void);
+};
+std::vector<Plugin>& plugins() {
+  static std::vector<Plugin> v;
+  return v;
+}
+std::mutex& plugins_mutex() {
+  static std::mutex m;
+  return m;
+}
+const Plugin* find_plugin(int id) {
+  std::lock_guard<std::mutex> g(plugins_mutex());
+  const int n = id - CGMRES_HIP_MODEL_USER_BASE;
+  return n >= 0 && n < int(plugins().size()) ? &plugins()[n] : nullptr;
+}
+
 cgm::ModelInfo model_info(int id, bool* ok) {
   *ok = true;
+  if (const Plugin* pl = find_plugin(id)) return pl->info;
   switch (id) {
     case CGMRES_HIP_MODEL_PENDULUM:
       return cgm::PendulumDev<double>::info();
@@ -42,6 +70,10 @@ int check_device(int device) {
 
 cgmres_hip_ctx* make_ctx(const cgmres_hip_config& cfg, int* resolved) {
   const bool f32 = cfg.dtype == CGMRES_HIP_F32;
+  if (const Plugin* pl = find_plugin(cfg.model_id)) {  // user models: the lane mapping only (user_model.hip.h)
+    *resolved = cfg.variant == 0 ? 1 : cfg.variant;
+    return *resolved == 1 ? pl->make(&cfg) : nullptr;
+  }
   switch (cfg.model_id) {
     case CGMRES_HIP_MODEL_PENDULUM:
       return f32 ? cgm::make_pendulum_f32(cfg, resolved) : cgm::make_pendulum_f64(cfg, resolved);
@@ -110,6 +142,12 @@ int cgmres_hip_model_probe(int32_t model_id, int32_t device, const double* x, co
   (void)hipMemcpy(du, u, mi.dim_u * 8, hipMemcpyHostToDevice);
   if (mi.dim_p) (void)hipMemcpy(dp, p, mi.dim_p * 8, hipMemcpyHostToDevice);
   (void)hipMemcpy(dl, lmd, mi.dim_x * 8, hipMemcpyHostToDevice);
+  if (const Plugin* pl = find_plugin(model_id)) {
+    if (pl->probe(dx, du, dp, dl, dout, nullptr) != 0) {
+      (void)hipFree(d);
+      return fail(CGMRES_HIP_ERUNTIME, "model_probe: plugin kernel launch failed");
+    }
+  } else
   switch (model_id) {
     case CGMRES_HIP_MODEL_PENDULUM:
       cgm::probe_kernel<cgm::PendulumDev<double>><<<1, 1>>>(dx, du, dp, dl, dout);
@@ -141,6 +179,47 @@ int cgmres_hip_selftest_sincos(int32_t device, const double* a, int32_t n, doubl
   return 0;
 }
 
+int cgmres_hip_register_model(const char* plugin_path, int32_t* model_id) {
+  if (!plugin_path || !model_id) return fail(CGMRES_HIP_EINVAL, "register_model: null argument");
+  {
+    std::lock_guard<std::mutex> g(plugins_mutex());
+    for (size_t n = 0; n < plugins().size(); ++n)
+      if (plugins()[n].path == plugin_path) {
+        *model_id = CGMRES_HIP_MODEL_USER_BASE + int(n);
+        return 0;
+      }
+  }
+  void* dl = dlopen(plugin_path, RTLD_NOW | RTLD_LOCAL);
+  if (!dl) return fail(CGMRES_HIP_EINVAL, "register_model: %s", dlerror());
+  auto abi = reinterpret_cast<int32_t (*)(void)>(dlsym(dl, "cgmres_hip_plugin_abi"));
+  auto info = reinterpret_cast<void (*)(int32_t*, double*)>(dlsym(dl, "cgmres_hip_plugin_info"));
+  Plugin pl{};
+  pl.dl = dl, pl.path = plugin_path;
+  pl.make = reinterpret_cast<decltype(pl.make)>(dlsym(dl, "cgmres_hip_plugin_make"));
+  pl.probe = reinterpret_cast<decltype(pl.probe)>(dlsym(dl, "cgmres_hip_plugin_probe"));
+  pl.last_error = reinterpret_cast<decltype(pl.last_error)>(dlsym(dl, "cgmres_hip_plugin_last_error"));
+  if (!abi || !info || !pl.make || !pl.probe || !pl.last_error) {
+    dlclose(dl);
+    return fail(CGMRES_HIP_EINVAL, "register_model: %s is not a cgmres_hip model plugin", plugin_path);
+  }
+  if (abi() != CGMRES_HIP_ABI_VERSION) {
+    dlclose(dl);
+    return fail(CGMRES_HIP_EINVAL, "register_model: plugin ABI %d, library has %d", abi(), CGMRES_HIP_ABI_VERSION);
+  }
+  int32_t dims[5];
+  double tun[6];
+  info(dims, tun);
+  pl.info = {dims[0], dims[1], dims[2], dims[3], dims[4], tun[0], tun[1], tun[2], tun[3], tun[4], tun[5]};
+  if (dims[0] < 1 || dims[1] < 1 || dims[2] < 0) {
+    dlclose(dl);
+    return fail(CGMRES_HIP_EINVAL, "register_model: bad dimensions %d/%d/%d", dims[0], dims[1], dims[2]);
+  }
+  std::lock_guard<std::mutex> g(plugins_mutex());
+  plugins().push_back(pl);
+  *model_id = CGMRES_HIP_MODEL_USER_BASE + int(plugins().size()) - 1;
+  return 0;
+}
+
 int cgmres_hip_create(const cgmres_hip_config* cfg, cgmres_hip_handle* out) {
   if (!cfg || !out) return fail(CGMRES_HIP_EINVAL, "create: null argument");
   *out = nullptr;
@@ -166,6 +245,7 @@ int cgmres_hip_create(const cgmres_hip_config* cfg, cgmres_hip_handle* out) {
   c->cfg = *cfg;
   c->cfg.variant = resolved;
   if (int rc = c->init()) {
+    if (const Plugin* pl = find_plugin(cfg->model_id)) cgm::g_err = pl->last_error();  // the plugin has its own copy
     delete c;
     return rc;
   }

@@ -11,6 +11,7 @@
 // go to an HBM scratch [stage][component][ldb] (L2 resident: 4096 x 2.8 KB = 11.6 MB); the costate
 // itself never leaves registers because dH/du(i) is evaluated inside the backward loop.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
@@ -39,6 +40,25 @@ enum FOut { F_PLAIN = 0, F_RHS = 1, F_AX = 2 };
 //   F_PLAIN: out = F                                   (cgmres.hpp:88)
 //   F_RHS  : out = (F*(1-zeta*h) - Fh) * (1/h)         (cgmres.hpp:91-96)
 //   F_AX   : out = (F - Fh) * (1/h)                    (cgmres.hpp:173-174)
+// The state equation of stage `stage`.  The built-in models do not read the time-varying parameter p in dxdt; a
+// user model compiled through the plugin path (user_model.hip.h) may (Model::dxdt(ret, x, u, p), */model.hpp:36).
+template <class M, class T, class = void>
+struct DxdtUsesP : std::false_type {};
+template <class M, class T>
+struct DxdtUsesP<M, T, std::enable_if_t<M::DXDT_USES_P>> : std::true_type {};
+template <class M, class T>
+__device__ __forceinline__ void state_eq(T* f, const T* x, const T* u, T* tr, const typename M::Math& mc,
+                                         const T* ptau, size_t ld, int stage) {
+  if constexpr (DxdtUsesP<M, T>::value) {
+    T p[M::NP > 0 ? M::NP : 1];
+#pragma unroll
+    for (int j = 0; j < M::NP; ++j) p[j] = ptau[size_t(stage * M::NP + j) * ld];
+    M::dxdt_p(f, x, u, p);
+  } else {
+    M::dxdt(f, x, u, tr, mc);
+  }
+}
+
 template <class M, class T, bool PERTURB, int MODE>
 __device__ __forceinline__ void f_eval_lane(const TickParams<T>& P, size_t ld, const T* __restrict__ U,
                                             const T* __restrict__ v, const T* x0, T dtau,
@@ -63,7 +83,7 @@ __device__ __forceinline__ void f_eval_lane(const TickParams<T>& P, size_t ld, c
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) traj[size_t(s * NX + i) * ld] = xs[i];
-    M::dxdt(f, xs, u, tr, mc);
+    state_eq<M, T>(f, xs, u, tr, mc, ptau, ld, s);
 #pragma unroll
     for (int c = 0; c < NC; ++c) trig[size_t(s * NC + c) * ld] = tr[c];
 #pragma unroll
@@ -122,7 +142,7 @@ __device__ __forceinline__ void prepare_lane(const TickParams<T>& P, size_t ld, 
   mc.init();
 #pragma unroll
   for (int j = 0; j < NU; ++j) u0[j] = A.U[size_t(j) * ld];
-  M::dxdt(f, x, u0, tr, mc);  // cgmres.hpp:83
+  state_eq<M, T>(f, x, u0, tr, mc, A.ptau, ld, 0);  // cgmres.hpp:83
 #pragma unroll
   for (int i = 0; i < NX; ++i) {
     xh[i] = f[i] * P.h + x[i];  // :84-85
@@ -271,7 +291,7 @@ __global__ __launch_bounds__(64) void tick_lane_kernel(TickParams<T> P) {
     T f[M::NX], tr[M::NC > 0 ? M::NC : 1];
     typename M::Math mc;
     mc.init();
-    M::dxdt(f, x, u, tr, mc);
+    state_eq<M, T>(f, x, u, tr, mc, A.ptau, ld, 0);
 #pragma unroll
     for (int i = 0; i < M::NX; ++i) P.x_next[size_t(b) * M::NX + i] = x[i] + f[i] * P.dt;
   }

@@ -26,6 +26,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "cgmres_hip.h"
 #include "gmres.hpp"
@@ -40,35 +41,54 @@ inline void check(int rc, const char* what) {
   }
 }
 
-// Registry lookup by numeric fingerprint of the user's Model (see file header).
+// Does registry entry `id` compute the user's Model?  Same dimensions and the same dxdt/dPhidx/dHdx/dHdu at two
+// probe points (host class vs device build, 1e-12 relative).
+template <class Model>
+inline bool model_matches(int32_t id, int32_t device) {
+  constexpr int nx = Model::dim_x, nu = Model::dim_u, np = Model::dim_p;
+  int32_t dims[5];
+  double tuning[6];
+  if (cgmres_hip_model_info(id, dims, tuning) != 0) return false;
+  if (dims[0] != nx || dims[1] != nu || dims[2] != np) return false;
+  for (int probe = 0; probe < 2; ++probe) {
+    double x[nx], u[nu], p[np + 1], l[nx], host[3 * nx + nu], dev[3 * nx + nu];
+    for (int i = 0; i < nx; ++i) x[i] = 0.3 + 0.37 * i + 0.21 * probe, l[i] = -0.4 + 0.29 * i - 0.13 * probe;
+    for (int j = 0; j < nu; ++j) u[j] = 0.11 + 0.23 * j + 0.17 * probe;
+    for (int j = 0; j < np + 1; ++j) p[j] = 0.7 - 0.45 * j + 0.05 * probe;
+    Model::dxdt(&host[0], x, u, p);
+    Model::dPhidx(&host[nx], x, p);
+    Model::dHdx(&host[2 * nx], x, u, p, l);
+    Model::dHdu(&host[3 * nx], x, u, p, l);
+    if (cgmres_hip_model_probe(id, device, x, u, p, l, dev) != 0) return false;
+    for (int k = 0; k < 3 * nx + nu; ++k) {
+      const double scale = fabs(host[k]) > 1.0 ? fabs(host[k]) : 1.0;
+      if (!(fabs(host[k] - dev[k]) <= 1e-12 * scale)) return false;
+    }
+  }
+  return true;
+}
+
+// Registry lookup by numeric fingerprint of the user's Model (see file header): the built-in models first, then the
+// plugins named in the environment variable CGMRES_HIP_MODEL_PLUGINS (':'-separated shared objects generated from
+// the user's own model.hpp by `python -m cgmres_cpp_amd.plugin`, registered through cgmres_hip_register_model).
 template <class Model>
 inline int32_t identify_model(int32_t device) {
-  constexpr int nx = Model::dim_x, nu = Model::dim_u, np = Model::dim_p;
-  for (int32_t id = 0; id < CGMRES_HIP_MODEL_COUNT; ++id) {
-    int32_t dims[5];
-    double tuning[6];
-    if (cgmres_hip_model_info(id, dims, tuning) != 0) continue;
-    if (dims[0] != nx || dims[1] != nu || dims[2] != np) continue;
-    bool same = true;
-    for (int probe = 0; probe < 2 && same; ++probe) {
-      double x[nx], u[nu], p[np + 1], l[nx], host[3 * nx + nu], dev[3 * nx + nu];
-      for (int i = 0; i < nx; ++i) x[i] = 0.3 + 0.37 * i + 0.21 * probe, l[i] = -0.4 + 0.29 * i - 0.13 * probe;
-      for (int j = 0; j < nu; ++j) u[j] = 0.11 + 0.23 * j + 0.17 * probe;
-      for (int j = 0; j < np + 1; ++j) p[j] = 0.7 - 0.45 * j + 0.05 * probe;
-      Model::dxdt(&host[0], x, u, p);
-      Model::dPhidx(&host[nx], x, p);
-      Model::dHdx(&host[2 * nx], x, u, p, l);
-      Model::dHdu(&host[3 * nx], x, u, p, l);
-      if (cgmres_hip_model_probe(id, device, x, u, p, l, dev) != 0) {
-        same = false;
-        break;
+  for (int32_t id = 0; id < CGMRES_HIP_MODEL_COUNT; ++id)
+    if (model_matches<Model>(id, device)) return id;
+  if (const char* env = getenv("CGMRES_HIP_MODEL_PLUGINS")) {
+    const char* a = env;
+    while (*a) {
+      const char* e = strchr(a, ':');
+      const size_t n = e ? size_t(e - a) : strlen(a);
+      char path[4096];
+      if (n > 0 && n < sizeof path) {
+        memcpy(path, a, n);
+        path[n] = 0;
+        int32_t id = -1;
+        if (cgmres_hip_register_model(path, &id) == 0 && model_matches<Model>(id, device)) return id;
       }
-      for (int k = 0; k < 3 * nx + nu; ++k) {
-        const double scale = fabs(host[k]) > 1.0 ? fabs(host[k]) : 1.0;
-        if (!(fabs(host[k] - dev[k]) <= 1e-12 * scale)) same = false;
-      }
+      a += n + (e ? 1 : 0);
     }
-    if (same) return id;
   }
   return -1;
 }

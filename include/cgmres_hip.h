@@ -37,7 +37,8 @@ enum {
   CGMRES_HIP_MODEL_PENDULUM = 0,   /* arm_type_inverted_pendulum/model.hpp == multiple_controller/model2.hpp */
   CGMRES_HIP_MODEL_MSD = 1,        /* mass_spring_damper/model.hpp        == multiple_controller/model1.hpp */
   CGMRES_HIP_MODEL_SEMIACTIVE = 2, /* semiactive_damper/model.hpp */
-  CGMRES_HIP_MODEL_COUNT = 3
+  CGMRES_HIP_MODEL_COUNT = 3,
+  CGMRES_HIP_MODEL_USER_BASE = 1000 /* ids of user models registered with cgmres_hip_register_model */
 };
 enum { CGMRES_HIP_F64 = 0, CGMRES_HIP_F32 = 1 };
 
@@ -90,6 +91,12 @@ int cgmres_hip_default_config(int32_t model_id, cgmres_hip_config* cfg);
  * user Model class against the registry: out = [dxdt(dim_x) | dPhidx(dim_x) | dHdx(dim_x) | dHdu(dim_u)]. */
 int cgmres_hip_model_probe(int32_t model_id, int32_t device, const double* x, const double* u, const double* p,
                            const double* lmd, double* out);
+/* Registers a USER model: `plugin_path` is a shared object generated from a reference-style Model header
+ * (static constexpr dim_x/.../tol and static dxdt/dPhidx/dHdx/dHdu/ddHduu, <example>/model.hpp:7-76) by
+ * cgmres_cpp_amd/plugin.py (hipcc, gfx950).  *model_id receives an id >= CGMRES_HIP_MODEL_USER_BASE that every
+ * other entry point accepts; such models run on the "lane" mapping in fp64.  Registering the same path twice
+ * returns the same id.  This is what a `Cgmres<Model>` facade binds for a Model that is not in the registry. */
+int cgmres_hip_register_model(const char* plugin_path, int32_t* model_id);
 /* Diagnostic: the device sin/cos the horizon sweeps use (fp64), evaluated at n host-supplied arguments. */
 int cgmres_hip_selftest_sincos(int32_t device, const double* a, int32_t n, double* s, double* c);
 const char* cgmres_hip_last_error(void);
