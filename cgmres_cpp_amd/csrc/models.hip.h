@@ -48,6 +48,28 @@ __device__ __forceinline__ double mul2(double a, double b) {  // a*b that hipcc 
   return d;
 }
 
+__device__ __forceinline__ float fma3(float a, float b, float c) {
+  float d;
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ float mul2(float a, float b) {
+  float d;
+  asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+// type-generic spellings of the builtins the quad sweep uses
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double rint_t(double a) { return __builtin_rint(a); }
+__device__ __forceinline__ float rint_t(float a) { return __builtin_rintf(a); }
+__device__ __forceinline__ double maxabs_t(double m, double a) { return __builtin_fmax(m, __builtin_fabs(a)); }
+__device__ __forceinline__ float maxabs_t(float m, float a) { return __builtin_fmaxf(m, __builtin_fabsf(a)); }
+__device__ __forceinline__ double xor_sign(double v, int flip) {
+  return __hiloint2double(__double2hiint(v) ^ flip, __double2loint(v));
+}
+__device__ __forceinline__ float xor_sign(float v, int flip) { return __int_as_float(__float_as_int(v) ^ flip); }
+
 // The 15 fp64 constants of the routine, held in VGPRs for the lifetime of a thread.  They are made opaque
 // to the optimiser on purpose: with the scalar register file saturated by the kernel's pointers hipcc would
 // otherwise re-materialise every constant in every stage (22 s_mov + 12 v_mov per sincos pair).
@@ -131,18 +153,46 @@ __device__ __forceinline__ void sincos_f64(double a, double* sn, double* cs) {
 // Per-scalar-type math context handed to the model functions.
 template <class T>
 struct MathCtx;
+// For the quad sweep both kernels are used in the common form  value = (1 + z*P(z)) * h,  P of NK coefficients:
+//   sin: h = r, P = S1 + S2 z + ...            cos: h = 1, P = -1/2 + C1 z + C2 z^2 + ...
+// kernel_coef(is_cos, i) is coefficient i of that P (zero-padded at the top for the shorter sin kernel);
+// fast_range is the |argument| bound of the two-constant Cody-Waite reduction.
 template <>
 struct MathCtx<double> : TrigConsts {
+  static constexpr int NK = 7;
+  static constexpr double fast_range = 1.0e5;
   __device__ __forceinline__ void sincos_pair(double a0, double a1, double* s0, double* c0, double* s1,
                                               double* c1) const {
     sincos2_f64(a0, a1, s0, c0, s1, c1, *this);
   }
+  __device__ __forceinline__ double kernel_coef(bool is_cos, int i) const {
+    const double sk[NK] = {S1, S2, S3, S4, S5, S6, 0.0}, ck[NK] = {-0.5, C1, C2, C3, C4, C5, C6};
+    return is_cos ? ck[i] : sk[i];
+  }
 };
+// fp32: Cephes sinf/cosf minimax kernels on [-pi/4, pi/4] (public domain), FMA-based two-constant reduction
+// (exact product n*PIO2_HI inside the fma), |a| < 1e4.  ~1 ulp; the fp32 parity bar is 1e-4 on u.
 template <>
-struct MathCtx<float> : NoConsts {
+struct MathCtx<float> {
+  static constexpr int NK = 4;
+  static constexpr float fast_range = 1.0e4f;
+  float inv_pio2, pio2_hi, pio2_lo, S1, S2, S3, C1, C2, C3;
+  __device__ __forceinline__ void init() {
+    inv_pio2 = 6.36619772367581382433e-01f;
+    pio2_hi = 1.57079637050628662109375f;   // float(pi/2)
+    pio2_lo = -4.37113882867379262e-8f;     // pi/2 - pio2_hi
+    S1 = -1.6666654611e-1f, S2 = 8.3321608736e-3f, S3 = -1.9515295891e-4f;
+    C1 = 4.166664568298827e-2f, C2 = -1.388731625493765e-3f, C3 = 2.443315711809948e-5f;
+    asm volatile("" : "+v"(inv_pio2), "+v"(pio2_hi), "+v"(pio2_lo));
+    asm volatile("" : "+v"(S1), "+v"(S2), "+v"(S3), "+v"(C1), "+v"(C2), "+v"(C3));
+  }
   __device__ __forceinline__ void sincos_pair(float a0, float a1, float* s0, float* c0, float* s1, float* c1) const {
     ::sincosf(a0, s0, c0);
     ::sincosf(a1, s1, c1);
+  }
+  __device__ __forceinline__ float kernel_coef(bool is_cos, int i) const {
+    const float sk[NK] = {S1, S2, S3, 0.0f}, ck[NK] = {-0.5f, C1, C2, C3};
+    return is_cos ? ck[i] : sk[i];
   }
 };
 
@@ -229,7 +279,7 @@ struct PendulumDev {
     const T n3 = __builtin_fma(dtau, l[1], (T(1.0) - dtau * C22) * l[3]);
     l[0] = n0, l[1] = n1, l[2] = n2, l[3] = n3;
   }
-  // --- state sweep over a DPP quad (fp64 only) -----------------------------------------------------------------
+  // --- state sweep over a DPP quad -----------------------------------------------------------------
   // The serial state sweep (2 sincos + ~17 flops per stage, model.hpp:37-42) is the longest phase of a tick, and one
   // wave issues ONE instruction of any kind per ~4.4 cycles, dependent or not (tools/ubench_issue.hip; a taken
   // branch costs 28 more) — so what counts is the number of instructions per stage, not their latency.
@@ -245,10 +295,11 @@ struct PendulumDev {
   // Stage-table writes (all lanes, no branch): x0,x2 -> slots 0,2 (same value from every lane); this lane's x1c
   // -> slot 1 from the x1-lanes, slot 3 from the d-lanes; the trig value -> slots 4 (sin d), 5 (cos d), 6 (cos x1)
   // and 3 (sin x1).  Slot 3 (x3) is never read: stage_coeffs does not use x[3] because q3 = 0.
-  static constexpr bool HAS_QUAD_SWEEP = sizeof(T) == 8;
+  static constexpr bool HAS_QUAD_SWEEP = true;
   static constexpr int QSLOT_XA = 0, QSLOT_XB = 2, QLANE_TRUE_X = 2;  // write2 slots; a lane whose x[1] is +x1
   struct QuadLane {
-    T k0, k1, k2, k3, k4, k5, k6;  // P(z) = k0 + z*(k1 + ... + z*k6)
+    static constexpr int NK = Math::NK;
+    T k[NK];                       // P(z) = k[0] + z*(k[1] + ... + z*k[NK-1])
     T hs, hc;                      // h = hs*r + hc
     T mp, mq, mr, ms;              // weight (mp*x2 + mq)*x2 + (mr*u0 + ms) of this lane's trig value in dxdt[3]
     T kap, sg;                     // arg = kap*x0 + x1c, x1c = sg*x1
@@ -256,9 +307,8 @@ struct PendulumDev {
     int slot_x1, slot_v;
     __device__ __forceinline__ void init(int rho, const Math& mc) {
       is_cos = rho & 1;
-      k0 = is_cos ? T(-0.5) : mc.S1, k1 = is_cos ? mc.C1 : mc.S2, k2 = is_cos ? mc.C2 : mc.S3;
-      k3 = is_cos ? mc.C3 : mc.S4, k4 = is_cos ? mc.C4 : mc.S5, k5 = is_cos ? mc.C5 : mc.S6;
-      k6 = is_cos ? mc.C6 : T(0);
+#pragma unroll
+      for (int i = 0; i < NK; ++i) k[i] = mc.kernel_coef(is_cos, i);
       hs = is_cos ? T(0) : T(1), hc = is_cos ? T(1) : T(0);
       mp = rho == 0 ? A32 : T(0), mq = rho == 1 ? A32a : T(0), mr = rho == 1 ? -A32b : T(0), ms = rho == 2 ? A52 : T(0);
       kap = rho < 2 ? T(1) : T(0), sg = rho < 2 ? T(-1) : T(1);
@@ -275,30 +325,28 @@ struct PendulumDev {
       ::sincos(double(arg), &sn, &cs);
       return Q.is_cos ? T(cs) : T(sn);
     } else {
-      *amax = __builtin_fmax(*amax, __builtin_fabs(arg));
-      const T n = __builtin_rint(arg * mc.inv_pio2);
-      T r = __builtin_fma(-n, mc.pio2_hi, arg);
-      r = __builtin_fma(-n, mc.pio2_lo, r);
+      constexpr int NK = QuadLane::NK;
+      *amax = maxabs_t(*amax, arg);
+      const T n = rint_t(arg * mc.inv_pio2);
+      T r = fma_t(-n, mc.pio2_hi, arg);
+      r = fma_t(-n, mc.pio2_lo, r);
       const int q = static_cast<int>(n);
       const T z = r * r;
-      T P = fma3(z, Q.k6, Q.k5);
-      P = fma3(z, P, Q.k4);
-      P = fma3(z, P, Q.k3);
-      P = fma3(z, P, Q.k2);
-      P = fma3(z, P, Q.k1);
-      P = fma3(z, P, Q.k0);
-      const T G = __builtin_fma(z, P, T(1.0));
+      T P = fma3(z, Q.k[NK - 1], Q.k[NK - 2]);
+#pragma unroll
+      for (int i = NK - 3; i >= 0; --i) P = fma3(z, P, Q.k[i]);
+      const T G = fma_t(z, P, T(1.0));
       const T h = fma3(Q.hs, r, Q.hc);
       const T mine = mul2(G, h);
       const T other = dpp_move<DPP_QUAD_SWAP1>(mine);  // the cos kernel of my angle if I am the sin lane, and v.v.
       const T pick = (q & 1) ? other : mine;            // sin = {s,c,-s,-c}[q&3], cos = {c,-s,-c,s}[q&3]
       const int flip = ((q + (Q.is_cos ? 1 : 0)) & 2) << 30;
-      return __hiloint2double(__double2hiint(pick) ^ flip, __double2loint(pick));
+      return xor_sign(pick, flip);
     }
   }
-  static __device__ __forceinline__ bool quad_arg_bad(T amax) { return !(amax < T(1.0e5)); }
+  static __device__ __forceinline__ bool quad_arg_bad(T amax) { return !(amax < T(Math::fast_range)); }
   // lane-local form of the state (x[1] <- sg*x1) and the first trig value
-  static __device__ __forceinline__ T quad_arg(const T* x, const QuadLane& Q) { return __builtin_fma(Q.kap, x[0], x[1]); }
+  static __device__ __forceinline__ T quad_arg(const T* x, const QuadLane& Q) { return fma_t(Q.kap, x[0], x[1]); }
   template <bool SLOW>
   static __device__ __forceinline__ T quad_begin(T* x, const QuadLane& Q, const Math& mc, T* amax) {
     x[1] = Q.sg * x[1];
@@ -308,14 +356,14 @@ struct PendulumDev {
   template <bool SLOW>
   static __device__ __forceinline__ void quad_stage(T* x, T& v, T u0, T dtau, T dtau1, const QuadLane& Q,
                                                     const Math& mc, T* amax) {
-    const T m = __builtin_fma(__builtin_fma(Q.mp, x[2], Q.mq), x[2], __builtin_fma(Q.mr, u0, Q.ms));
+    const T m = fma_t(fma_t(Q.mp, x[2], Q.mq), x[2], fma_t(Q.mr, u0, Q.ms));
     const T trig_sum = quad_sum(mul2(m, v));  // mul2: the same rounded product in every lane of the quad
-    const T f3 = __builtin_fma(C22, x[2] - x[3], trig_sum);
-    const T f2 = __builtin_fma(-As, x[2], Bs * u0);
-    x[0] = __builtin_fma(dtau, x[2], x[0]);
-    x[1] = __builtin_fma(dtau1, x[3], x[1]);
-    x[2] = __builtin_fma(dtau, f2, x[2]);
-    x[3] = __builtin_fma(dtau, f3, x[3]);
+    const T f3 = fma_t(C22, x[2] - x[3], trig_sum);
+    const T f2 = fma_t(-As, x[2], Bs * u0);
+    x[0] = fma_t(dtau, x[2], x[0]);
+    x[1] = fma_t(dtau1, x[3], x[1]);
+    x[2] = fma_t(dtau, f2, x[2]);
+    x[3] = fma_t(dtau, f3, x[3]);
     v = quad_trig<SLOW>(quad_arg(x, Q), Q, mc, amax);
   }
   static __device__ __forceinline__ void ddHduu(T* m, const T*, const T* u, const T*, const T*) {  // :64-76
