@@ -503,6 +503,27 @@ struct WgCtx {
 
   // One complete sweep on the LDS table.  COLLECTIVE: every thread of the block must call it (two workgroup barriers
   // inside); the caller adds the barrier that publishes `out`.  x0c = initial state, component-major LDS [c*IPW + i].
+  // `after_sweep` runs on the sweep wave right after its state sweep, i.e. while it would otherwise wait for the other
+  // waves to finish the last coefficient chunk (gmres() requests its basis rows there); the barrier that follows
+  // orders LDS only so those loads stay in flight during the costate sweep.
+  template <bool PERT, int MODE, class After>
+  __device__ __forceinline__ void f_eval(const T* x0c, T dtau, T* out, bool only_active, After&& after_sweep) {
+    if constexpr (IPW * 16 >= 128) {
+      if (tid < 64) {
+        sweep_state<PERT, true>(0, x0c, dtau, S.R, S.xT, only_active);
+        after_sweep();
+      } else {
+        coeffs_chunked<PERT, MODE>(dtau, out, only_active);
+      }
+      CGM_STAMP(*this, 4);
+      lds_barrier();
+      CGM_STAMP(*this, 5);
+      sweep_costate<MODE>(dtau, S.xT, out, only_active);
+    } else {
+      f_eval<PERT, MODE>(x0c, dtau, out, only_active);
+      if (tid < 64) after_sweep();
+    }
+  }
   template <bool PERT, int MODE>
   __device__ __forceinline__ void f_eval(const T* x0c, T dtau, T* out, bool only_active) {
     if constexpr (IPW * 16 >= 128) {
@@ -594,11 +615,15 @@ struct WgCtx {
     }
   }
   // Ax_func in place on W (cgmres.hpp:164-175).  Collective; ends with W published.
-  __device__ __forceinline__ void ax(bool only_active) {
+  template <class After>
+  __device__ __forceinline__ void ax(bool only_active, After&& after_sweep) {
     CGM_STAMP(*this, 3);
-    f_eval<true, F_AX>(S.xh, P.dtau_h, S.W, only_active);
+    f_eval<true, F_AX>(S.xh, P.dtau_h, S.W, only_active, after_sweep);
     __syncthreads();
     CGM_STAMP(*this, 6);
+  }
+  __device__ __forceinline__ void ax(bool only_active) {
+    ax(only_active, [] {});
   }
 
   // Gmres::gmres (gmres.hpp:28-112).  In: x (registers `xv`), b (`bb`) and A*x0 (`ax0`), all in the row layout.
@@ -663,14 +688,19 @@ struct WgCtx {
         if (!any) break;
       }
       CGM_STAMP(*this, 15);
-      // The first basis vectors this iteration needs are requested from HBM/L2 NOW: they arrive while wave 0 sweeps.
+      // The first basis vectors this iteration needs are requested from HBM/L2 early.  Waves 1-3 do it NOW (the rows
+      // arrive while wave 0 sweeps); wave 0 — four waves' row requests take the CU's address unit ~800 cycles, which
+      // would delay the sweep — does it after its state sweep, where it otherwise waits for the coefficient tail.
       T vbuf[NBUF][MAXM];
-      if (preload && active) {
+      auto request_rows = [&]() {
+        if (preload && active) {
 #pragma unroll
-        for (int i = 0; i < NBUF; ++i)
-          if (i < k) load_vec(vbuf[i], vrow(i));
-      }
-      ax(true);  // :48  W <- A v_k, in place
+          for (int i = 0; i < NBUF; ++i)
+            if (i < k) load_vec(vbuf[i], vrow(i));
+        }
+      };
+      if (tid >= 64) request_rows();
+      ax(true, request_rows);  // :48  W <- A v_k, in place
       if (active) {
         lds_to_reg(w, S.W);
         T* Hk = Hi + k1 * k;
