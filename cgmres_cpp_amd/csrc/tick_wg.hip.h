@@ -259,6 +259,15 @@ struct WgCtx {
   // phase 1 writes x(s), trig(s) to `tab` — the LDS table S.R or, for the concurrent preamble sweeps, a per-workgroup
   // table in HBM — phase 2 reads `tab` and leaves the costate coefficients in S.R, phase 3 consumes S.R.
 
+  // value of lane `src` (a lane of this wave) through the LDS crossbar
+  static __device__ __forceinline__ double row_bcast(double v, int src) {
+    const int lo = __builtin_amdgcn_ds_bpermute(src * 4, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(src * 4, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+  }
+  static __device__ __forceinline__ float row_bcast(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src * 4, __float_as_int(v)));
+  }
   // Workgroup barrier that orders LDS only.  __syncthreads() also drains the wave's outstanding HBM traffic
   // (s_waitcnt vmcnt(0)); inside a sweep nothing another wave needs travels through HBM.
   __device__ __forceinline__ void lds_barrier() const {
@@ -823,8 +832,22 @@ struct WgCtx {
         if (j < ks) load_vec(vbx[j], vrow(j));
     }
     if (valid && reason <= 1) {
-      // back substitution (gmres.hpp:100-107): lane 0 of the row, in LDS
-      if (r == 0) {
+      // back substitution (gmres.hpp:100-107), column-oriented over the lanes of the row: lane j owns e_j; step i
+      // (descending) turns e_i into y_i = e_i / H_ii, broadcasts it inside the row (ds_bpermute) and every lane j < i
+      // subtracts H(j,i) y_i — for a fixed j the subtractions come in the reference's order (i = ks-1 ... j+1).
+      // One LDS read + one crossbar round trip per step instead of a dependent LDS chain of length ks-i on lane 0.
+      if (kmax <= 15) {
+        T e = r < ks ? rhoi[r] : T(0);
+        const int row_lane0 = (threadIdx.x & 63) & ~15;
+        for (int i = ks - 1; i >= 0; --i) {
+          const T hii = Hi[k1 * i + i], hji = Hi[k1 * i + r];  // r <= 15 stays inside H (k1*k1 words, i < k1-1)
+          const T y = e / hii;                                   // meaningful in lane i
+          const T yi = row_bcast(y, row_lane0 + i);
+          e = r < i ? e - hji * yi : (r == i ? y : e);
+        }
+        if (r < ks) rhoi[r] = e;
+        if (r == 0) S.ksolve[inst] = ks;
+      } else if (r == 0) {
         for (int i = ks - 1; i >= 0; --i) {
           T ei = rhoi[i];
           for (int j = ks - 1; j > i; --j) ei -= Hi[k1 * j + i] * rhoi[j];
