@@ -783,16 +783,18 @@ struct WgCtx {
           CGM_STAMP(*this, 8);
           T en;
           {
+            // The running entry stays in a register (a) and only ORIGINAL column entries / reflector words are read
+            // from LDS, one step ahead: no store-to-load round trip through LDS between consecutive reflectors.
+            T a = Hk[0];
+            T g0n = gi[0], g1n = gi[1], g2n = gi[2], cn = Hk[1];
             for (int i = 0; i < k; ++i) {
-              const T g0 = gi[3 * i], g1 = gi[3 * i + 1], g2 = gi[3 * i + 2];
-              const T a = Hk[i], c = Hk[i + 1];
+              const T g0 = g0n, g1 = g1n, g2 = g2n, c = cn;
+              g0n = gi[3 * i + 3], g1n = gi[3 * i + 4], g2n = gi[3 * i + 5], cn = Hk[i + 2];  // i+1 <= k: in range
               const T beta = (g0 * a + g1 * c) * g2;
-              if (r == 0) {
-                Hk[i] = a - beta * g0;
-                Hk[i + 1] = c - beta * g1;
-              }
+              if (r == 0) Hk[i] = a - beta * g0;
+              a = c - beta * g1;
             }
-            const T a = Hk[k], c = Hk[k + 1];
+            const T c = hn;
             const T sigma = -(a < T(0.0) ? T(-1.0) : T(1.0)) * sqrt_t<T>(a * a + c * c);
             const T g0 = a - sigma, g1 = c;
             const T g2 = T(2.0) / (g0 * g0 + g1 * g1);

@@ -16,6 +16,7 @@ __global__ void k(double* out, long long* cyc, int iters, double b, double c) {
   __shared__ double lds[2048];
   lds[threadIdx.x] = a;
   __syncthreads();
+  double* gp = out + 4096 + (threadIdx.x >> 2) * 2;
   int addr = (threadIdx.x >> 2) * 8, addr2 = threadIdx.x * 8, addr3 = threadIdx.x * 16;
   long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
@@ -68,12 +69,16 @@ __global__ void k(double* out, long long* cyc, int iters, double b, double c) {
     if (TEST == 34) asm volatile(REPT(64, "ds_write2_b64 %1, %0, %0 offset1:16") : : "v"(a), "v"(addr2) : "memory");
     if (TEST == 35) asm volatile(REPT(64, "ds_read_b128 %0, %1") : "=v"(i128) : "v"(addr3) : "memory");
     if (TEST == 36) asm volatile(REPT(32, "ds_write_b64 %1, %0\n v_fma_f64 %2, %2, %3, %4\n v_fma_f64 %2, %2, %3, %4\n v_fma_f64 %2, %2, %3, %4") : : "v"(a), "v"(addr2), "v"(d), "v"(b), "v"(c) : "memory");
+    if (TEST == 37) asm volatile(REPT(64, "global_store_dwordx2 %1, %0, off") : : "v"(a), "v"(gp) : "memory");
+    if (TEST == 38) asm volatile(REPT(64, "global_store_dwordx4 %1, %0, off") : : "v"(i128), "v"(gp) : "memory");
+    if (TEST == 39) asm volatile(REPT(32, "global_store_dwordx2 %1, %0, off\n v_fma_f64 %2, %2, %3, %4\n v_fma_f64 %2, %2, %3, %4\n v_fma_f64 %2, %2, %3, %4") : : "v"(a), "v"(gp), "v"(d), "v"(b), "v"(c) : "memory");
+    if (TEST == 40) asm volatile(REPT(64, "global_load_dwordx2 %0, %1, off") : "=v"(a) : "v"(gp) : "memory");
     if (TEST == 29) asm volatile(REPT(64, "ds_read2_b64 %0, %1 offset1:16") : "=v"(i128) : "v"(addr) : "memory");
     if (TEST == 30) asm volatile(REPT(64, "ds_read_b64 %0, %1") : "=v"(a) : "v"(addr) : "memory");
   }
   long long t1 = __builtin_readcyclecounter();
   if (TEST == 14 || TEST == 15) __syncthreads();
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   out[blockIdx.x * blockDim.x + threadIdx.x] = i128[0] + a + d + e + f + i0 + i1 + lds[(threadIdx.x * 7) & 1023];
   if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
 }
@@ -130,6 +135,10 @@ int main() {
   run<34>("ds_write2_b64 lane-contiguous", 64);
   run<35>("ds_read_b128 lane-contiguous (no wait)", 64);
   run<36>("ds_write_b64 + 3 v_fma_f64 (per 4 instr)", 128);
+  run<37>("global_store_dwordx2, 4 lanes/address", 64);
+  run<38>("global_store_dwordx4, 4 lanes/address", 64);
+  run<39>("global_store_dwordx2 + 3 v_fma_f64 (per 4 instr)", 128);
+  run<40>("global_load_dwordx2 back to back (L1/L2 hit)", 64);
   run<29>("ds_read2_b64 back to back (no wait)", 64);
   run<30>("ds_read_b64 back to back (no wait)", 64);
   return 0;
