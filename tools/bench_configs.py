@@ -56,3 +56,37 @@ for args in [(2, 4096, 50, 10, "f64"), (1, 4096, 50, 10, "f64"), (0, 4096, 50, 1
     for tol in (0.0, 1e-6):
         out.append(run(*args, tol))
         print(json.dumps(out[-1]), flush=True)
+
+
+def run_mixed(B_each=4096, dv=50, kmax=10, tol=0.0, steps=100, warmup=50):
+    """BASELINE configs[4] on ONE GPU: Model1 (MSD) and Model2 (pendulum) batches stepped in the same loop on two
+    streams (multiple_controller/main.cpp:104-110), host wall clock around both."""
+    from cgmres_cpp_amd.multi import MultipleController
+    dev = torch.device("cuda", 0)
+    mc = MultipleController([dict(model=1, batch=B_each, dv=dv, k_max=kmax, tol=tol),
+                             dict(model=0, batch=B_each, dv=dv, k_max=kmax, tol=tol)])
+    xs, us = [], []
+    for m, mid in zip(mc.members, (1, 0)):
+        x0, u0, p = scenarios.batch(NAMES[mid], B_each)
+        if DIMS[mid][2]:
+            m.set_ptau_repeat(p)
+        m.init_u0(u0)
+        m.init_u0_newton(u0, x0, p, 10)
+        xs.append(torch.from_numpy(x0).to(dev))
+        us.append(torch.zeros(B_each, DIMS[mid][1], dtype=torch.float64, device=dev))
+    mc.closed_loop_device(xs, us, warmup)
+    mc.synchronize()
+    t0 = time.perf_counter()
+    mc.closed_loop_device(xs, us, steps)
+    mc.synchronize()
+    dt = time.perf_counter() - t0
+    ok = all(bool(torch.isfinite(u).all().item()) for u in us)
+    by = B_each * (alg_bytes(1, dv, kmax, 8) + alg_bytes(0, dv, kmax, 8))
+    mc.close()
+    return {"model": "msd+pendulum (two streams)", "batch": 2 * B_each, "dv": dv, "kmax": kmax, "dtype": "f64",
+            "tol": tol, "variant": 2, "ms_per_tick": dt / steps * 1e3, "steps_per_s": 2 * B_each * steps / dt,
+            "mean_arnoldi_last_tick": float(kmax), "algorithmic_GBps": by / (dt / steps) / 1e9,
+            "frac_of_8TBps": by / (dt / steps) / 1e9 / 8000.0, "finite": ok}
+
+
+print(json.dumps(run_mixed()), flush=True)
