@@ -5,7 +5,7 @@ namespace cgm {
 cgmres_hip_ctx* make_pendulum_f64(const cgmres_hip_config& cfg, int* resolved) {
   return make_variant<PendulumDev<double>, double>(cfg, resolved);
 }
-#ifdef CGM_STAMPS
+#if defined(CGM_STAMPS) && (!defined(CGM_STAMPS_MODEL) || CGM_STAMPS_MODEL == 0)
 long long* debug_stamps_ptr() {
   void* p = nullptr;
   return hipGetSymbolAddress(&p, HIP_SYMBOL(g_cgm_stamps)) == hipSuccess ? static_cast<long long*>(p) : nullptr;

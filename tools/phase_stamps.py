@@ -9,13 +9,14 @@ from cgmres_cpp_amd import build as b
 
 diag = os.path.join(ROOT, "_diag")  # git-ignored, but travels with gpurun (gpurun_out/ does not)
 os.makedirs(diag, exist_ok=True)
-lib = os.path.join(diag, "libcgmres_hip_stamps.so")
+MODEL = "msd" if "--model=msd" in sys.argv else "pendulum"
+lib = os.path.join(diag, f"libcgmres_hip_stamps_{MODEL}.so")
 if "--build" in sys.argv or "--build-only" in sys.argv or not os.path.exists(lib):
     srcs, _ = b.sources()
     from concurrent.futures import ThreadPoolExecutor
     def cc(s):
-        o = os.path.join(diag, os.path.basename(s)[:-4] + ".o")
-        subprocess.run([b.HIPCC] + b.CFLAGS + ["-DCGM_STAMPS", "-c", "-o", o, s], check=True)
+        o = os.path.join(diag, os.path.basename(s)[:-4] + f"_{MODEL}.o")
+        subprocess.run([b.HIPCC] + b.CFLAGS + ["-DCGM_STAMPS", f"-DCGM_STAMPS_MODEL={1 if MODEL == 'msd' else 0}", "-c", "-o", o, s], check=True)
         return o
     with ThreadPoolExecutor(8) as ex:
         objs = list(ex.map(cc, srcs))
@@ -26,10 +27,10 @@ b.LIB_PATH = lib
 import cgmres_cpp_amd as cg
 from cgmres_cpp_amd import scenarios
 B = 4096
-x0, u0, p = scenarios.batch("pendulum", B)
-c = cg.CgmresBatch("pendulum", batch=B, dv=50, k_max=10, tol=0.0)
+x0, u0, p = scenarios.batch(MODEL, B)
+c = cg.CgmresBatch(MODEL, batch=B, dv=50, k_max=10, tol=0.0)
 c.set_ptau_repeat(p); c.init_u0(u0); c.init_u0_newton(u0, x0, p, 10)
-xd = c.device_buffer((B, 4)).upload(x0); ud = c.device_buffer((B, 3))
+xd = c.device_buffer(x0.shape).upload(x0); ud = c.device_buffer(u0.shape)
 c.closed_loop_device(xd, ud, 50); c.synchronize()
 L = cg.load()
 out = (ctypes.c_longlong * 64)()
