@@ -371,20 +371,44 @@ struct WgCtx {
 #pragma unroll
         for (int c = 0; c < NX; ++c) xs[c] = x0c[c * IPW + i];
       }
+      // Same loop shape as the quad sweep: two stages per trip, the controls of the next stage fetched one stage
+      // ahead (the words after the last stage belong to the row's pad / the next row: in-bounds, unused), walking
+      // pointers so the second stage of a trip addresses with immediates.
+      struct Uc {
+        T v[M::NU_DYN];
+      };
+      T* pr = R;
+      const T* pu = U;
+      auto fetch = [&](Uc& a, const T* q) {
+#pragma unroll
+        for (int j = 0; j < M::NU_DYN; ++j) a.v[j] = q[j];
+      };
+      auto stage = [&](const Uc& a, T* q) {
+        T f[NX], tr[NC > 0 ? NC : 1];
+#pragma unroll
+        for (int c = 0; c < NX; ++c) q[c * IPW] = xs[c];
+        M::dxdt(f, xs, a.v, tr, mc);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) q[(NX + c) * IPW] = tr[c];
+#pragma unroll
+        for (int c = 0; c < NX; ++c) xs[c] = f[c] * dtau + xs[c];
+      };
+      Uc ua, ub;
+      if (go) fetch(ua, pu);
       for (int s0 = 0; s0 < dv; s0 += CH) {
-        const int s1 = s0 + CH < dv ? s0 + CH : dv;
+        const int n = dv - s0 < CH ? dv - s0 : CH;
         if (go) {
-          for (int s = s0; s < s1; ++s) {
-            T u[M::NU_DYN], f[NX], tr[NC > 0 ? NC : 1];
-#pragma unroll
-            for (int j = 0; j < M::NU_DYN; ++j) u[j] = U[s * NU + j];
-#pragma unroll
-            for (int c = 0; c < NX; ++c) R[(s * NSTG + c) * IPW] = xs[c];
-            M::dxdt(f, xs, u, tr, mc);
-#pragma unroll
-            for (int c = 0; c < NC; ++c) R[(s * NSTG + NX + c) * IPW] = tr[c];
-#pragma unroll
-            for (int c = 0; c < NX; ++c) xs[c] = f[c] * dtau + xs[c];
+          int k = 0;
+          for (; k + 2 <= n; k += 2) {
+            fetch(ub, pu + NU);
+            stage(ua, pr);
+            fetch(ua, pu + 2 * NU);
+            stage(ub, pr + STEP);
+            pr += 2 * STEP, pu += 2 * NU;
+          }
+          if (k < n) {  // odd tail (last chunk only)
+            stage(ua, pr);
+            pr += STEP, pu += NU;
           }
         }
         if (PIPE) lds_barrier();
