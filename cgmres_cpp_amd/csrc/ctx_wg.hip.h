@@ -40,14 +40,23 @@ struct CtxWg final : cgmres_hip_ctx {
     k_hook = hook_wg_kernel<M, T, IPW, MAXM>;
     ipw = IPW, maxm = MAXM;
   }
-  static bool supported(const cgmres_hip_config& c, int* ipw_out, size_t* bytes_out) {
+  // Preference: 16 instances per workgroup with everything in LDS; 16 with F(U,x+hf,t+h) in HBM (WgLds::count_T);
+  // 8 instances per workgroup.
+  static bool supported(const cgmres_hip_config& c, int* ipw_out, size_t* bytes_out, int* fh_hbm_out = nullptr) {
     const int L = M::NU * c.dv;
     if (L > 320) return false;
     const int Lp = L | 1, Pp = (M::NP * (c.dv + 1)) | 1, Hp = ((c.k_max + 1) * (c.k_max + 1)) | 1;
     const size_t b16 = WgLds<M, T, 16>::bytes(c.dv, c.k_max, Lp, Pp, Hp);
+    const size_t b16h = WgLds<M, T, 16>::bytes(c.dv, c.k_max, Lp, Pp, Hp, 1);
     const size_t b8 = WgLds<M, T, 8>::bytes(c.dv, c.k_max, Lp, Pp, Hp);
+    if (fh_hbm_out) *fh_hbm_out = 0;
     if (b16 <= kLdsLimit) {
       *ipw_out = 16, *bytes_out = b16;
+      return true;
+    }
+    if (L > 160 && b16h <= kLdsLimit) {  // the long-vector kernels (MAXM = 20) are the ones that carry this mode
+      *ipw_out = 16, *bytes_out = b16h;
+      if (fh_hbm_out) *fh_hbm_out = 1;
       return true;
     }
     if (b8 <= kLdsLimit) {
@@ -62,7 +71,8 @@ struct CtxWg final : cgmres_hip_ctx {
     nx = M::NX, nu = M::NU, np = M::NP;
     L = nu * cfg.dv;
     int want = 0;
-    if (!supported(cfg, &want, &lds_bytes))
+    int fh_hbm = 0;
+    if (!supported(cfg, &want, &lds_bytes, &fh_hbm))
       return fail(CGMRES_HIP_EINVAL, "wg mapping: dim_u*dv = %d / LDS footprint not supported", L);
     const bool big = L > 160;
     if (want == 16 && !big) pick<16, 10>();
@@ -75,7 +85,7 @@ struct CtxWg final : cgmres_hip_ctx {
                                 int(lds_bytes)));
     const int k1 = cfg.k_max + 1;
     ks_all = k1 * k1 + k1 + 3 * cfg.k_max;
-    P.B = cfg.batch, P.dv = cfg.dv, P.kmax = cfg.k_max, P.L = L;
+    P.B = cfg.batch, P.dv = cfg.dv, P.kmax = cfg.k_max, P.L = L, P.fh_hbm = fh_hbm;
     P.Lp = L | 1, P.Lg = (L + 15) / 16 * 16, P.Lv = 16 * maxm, P.Pp = (np * (cfg.dv + 1)) | 1, P.Hp = (k1 * k1) | 1;
     P.h = T(cfg.h), P.dt = T(cfg.dt), P.tol = T(cfg.tol);
     P.inv_h = T(1.0) / P.h;

@@ -37,7 +37,8 @@ enum WgMode { WG_TICK = 0, WG_HOOK_F = 1, WG_HOOK_PREPARE = 2, WG_HOOK_AX = 3, W
 
 template <class T>
 struct WgParams {
-  int B, dv, kmax, L, Lp, Lg, Lv, Pp, Hp;  // Lp/Pp/Hp: odd LDS row pitches; Lg: global row pitch (multiple of 16);
+  int B, dv, kmax, L, Lp, Lg, Lv, Pp, Hp, fh_hbm;  // fh_hbm: F(U,x+hf,t+h) is kept in HBM only (P.Fh), see WgLds
+   // Lp/Pp/Hp: odd LDS row pitches; Lg: global row pitch (multiple of 16);
                                         // Lv = 16*MAXM: pitch of the Krylov rows (pads kept zero, no guards)
   T h, dt, tol, inv_h, one_m_zh, dtau_h, dtau_0;
   // instance-major HBM state
@@ -89,19 +90,21 @@ struct WgLds {
   static constexpr int NSTG = (M::NX + M::NC) > M::NBW ? (M::NX + M::NC) : M::NBW;
   T *U, *Fh, *W, *R, *p, *H, *rho, *g, *xs, *xh, *xT;  // xT: terminal state of the last state sweep
   int *flag, *reason, *nax, *ksolve;
-  static __host__ __device__ size_t count_T(int dv, int kmax, int Lp, int Pp, int Hp) {
+  // fh_hbm: the row array of F(U, x+hf, t+h) is left out of LDS — the coefficient phase, its only reader after the
+  // preamble, takes it from HBM (P.Fh).  Used when that is what lets 16 instances fit (MSD at N = 50: L = 300).
+  static __host__ __device__ size_t count_T(int dv, int kmax, int Lp, int Pp, int Hp, int fh_hbm = 0) {
     const int k1 = kmax + 1;
-    return size_t(3) * IPW * Lp + size_t(dv) * NSTG * IPW + size_t(IPW) * Pp + size_t(IPW) * Hp + size_t(IPW) * k1 +
+    return size_t(fh_hbm ? 2 : 3) * IPW * Lp + size_t(dv) * NSTG * IPW + size_t(IPW) * Pp + size_t(IPW) * Hp + size_t(IPW) * k1 +
            size_t(IPW) * 3 * kmax + size_t(5) * M::NX * IPW;
   }
-  static __host__ __device__ size_t bytes(int dv, int kmax, int Lp, int Pp, int Hp) {
-    return count_T(dv, kmax, Lp, Pp, Hp) * sizeof(T) + 4 * IPW * sizeof(int) + 16;
+  static __host__ __device__ size_t bytes(int dv, int kmax, int Lp, int Pp, int Hp, int fh_hbm = 0) {
+    return count_T(dv, kmax, Lp, Pp, Hp, fh_hbm) * sizeof(T) + 4 * IPW * sizeof(int) + 16;
   }
-  __device__ __forceinline__ WgLds(unsigned char* base, const WgParams<T>& P) {
+  __device__ __forceinline__ WgLds(unsigned char* base, const WgParams<T>& P, bool fh_hbm) {
     T* q = reinterpret_cast<T*>(base);
     const int k1 = P.kmax + 1;
     U = q, q += IPW * P.Lp;
-    Fh = q, q += IPW * P.Lp;
+    Fh = q, q += fh_hbm ? 0 : IPW * P.Lp;  // fh_hbm: Fh aliases W (the preamble moves the result to HBM)
     W = q, q += IPW * P.Lp;
     R = q, q += P.dv * NSTG * IPW;
     p = q, q += IPW * P.Pp;
@@ -130,7 +133,7 @@ struct WgCtx {
   typename M::Math mc;  // per-thread math context (pinned sin/cos constants); A/B: keeping it live for the whole
                         // kernel is 13 us/tick FASTER than re-creating it inside every sweep
   __device__ __forceinline__ WgCtx(const WgParams<T>& P_, unsigned char* smem)
-      : P(P_), S(smem, P_), tid(threadIdx.x), inst(threadIdx.x >> 4), r(threadIdx.x & 15) {
+      : P(P_), S(smem, P_, MAXM > 10 && P_.fh_hbm), tid(threadIdx.x), inst(threadIdx.x >> 4), r(threadIdx.x & 15) {
     b = blockIdx.x * IPW + inst;
     valid = b < P.B;
     bi = blockIdx.x * IPW + tid;
@@ -259,6 +262,9 @@ struct WgCtx {
   // phase 1 writes x(s), trig(s) to `tab` — the LDS table S.R or, for the concurrent preamble sweeps, a per-workgroup
   // table in HBM — phase 2 reads `tab` and leaves the costate coefficients in S.R, phase 3 consumes S.R.
 
+  // The Fh-in-HBM mode only exists in the long-vector instantiations (L > 160 is where LDS gets tight); the short ones
+  // compile it out, so the headline kernel carries none of its branches.
+  __device__ __forceinline__ bool fh_hbm() const { return MAXM > 10 && P.fh_hbm; }
   // value of lane `src` (a lane of this wave) through the LDS crossbar
   static __device__ __forceinline__ double row_bcast(double v, int src) {
     const int lo = __builtin_amdgcn_ds_bpermute(src * 4, __double2loint(v));
@@ -450,7 +456,18 @@ struct WgCtx {
 #pragma unroll
     for (int j = 0; j < NU; ++j) {
       T rj = phi[j];
-      if (MODE != F_PLAIN) rj = (rj * sc_phi - S.Fh[i * P.Lp + s * NU + j]) * P.inv_h;
+      if (MODE != F_PLAIN) {
+        // two loads from two address spaces, selected by VALUE (a select of the pointers would have to go through
+        // the flat aperture); with fh_hbm the LDS word read is a word of W and is not used
+        T fh = S.Fh[i * P.Lp + s * NU + j];
+        if (fh_hbm()) {
+          // explicitly global: left generic, hipcc merges this pointer with the LDS one and trips over the flat
+          // aperture cast ("Illegal instruction detected ... $src_shared_base", ROCm 7.2)
+          typedef const T __attribute__((address_space(1))) * GPtr;
+          fh = reinterpret_cast<GPtr>(reinterpret_cast<uintptr_t>(P.Fh))[size_t(blockIdx.x * IPW + i) * P.Lg + s * NU + j];
+        }
+        rj = (rj * sc_phi - fh) * P.inv_h;
+      }
       out[i * P.Lp + s * NU + j] = rj;
     }
   }
@@ -600,7 +617,7 @@ struct WgCtx {
   // Results: Fh in S.Fh; b and Ax0 delivered in registers (row layout) because both pass through S.W.
   // COLLECTIVE; needs at least 3 waves (falls back to sequential sweeps otherwise).
   template <bool WITH_AX0>
-  __device__ __forceinline__ void preamble(T* bb, T* ax0) {
+  __device__ __forceinline__ void preamble(T* bb, T* ax0, const T* dir = nullptr) {  // dir: registers of the W direction
     make_xh();
     __syncthreads();
     if constexpr (IPW * 16 >= 192) {
@@ -614,10 +631,21 @@ struct WgCtx {
       __threadfence_block();
       __syncthreads();  // drains vmcnt: the HBM tables are complete and visible to the other waves of this CU
       CGM_STAMP(*this, 4);
-      sweep_coeffs<false, F_PLAIN>(P.dtau_h, S.R, S.Fh, false);
+      sweep_coeffs<false, F_PLAIN>(P.dtau_h, S.R, S.Fh, false);  // (S.Fh is S.W itself when fh_hbm)
       __syncthreads();
       sweep_costate<F_PLAIN>(P.dtau_h, xT0, S.Fh, false);
       __syncthreads();
+      if (fh_hbm()) {
+        // Fh went through W: move it to its HBM row and put the direction of A*x0 back (its first copy served the
+        // concurrent state sweep #3; the coefficient phase of #3 reads it again)
+        T fh[MAXM];
+        lds_to_reg(fh, S.W);
+        reg_to_row(P.Fh, P.Lg, fh);
+        __threadfence_block();
+        __syncthreads();  // drains vmcnt: the rows are visible to the other waves of this CU
+        if (WITH_AX0) publish_direction(dir);
+        __syncthreads();
+      }
       if (WITH_AX0) {
         sweep_coeffs<true, F_AX>(P.dtau_h, tab1, S.W, false);
         __syncthreads();
@@ -949,7 +977,7 @@ __global__ __launch_bounds__(IPW * 16) __attribute__((amdgpu_waves_per_eu(1, 1))
   CGM_STAMP(C, 0);
   C.publish_direction(du);  // direction of the first mat-vec: x0 = dUdt (warm start, cgmres.hpp:99)
   T ax0[MAXM];
-  C.template preamble<true>(bb, ax0);  // Fh in LDS; b and A*dUdt in registers
+  C.template preamble<true>(bb, ax0, du);  // Fh in LDS (or HBM); b and A*dUdt in registers
   CGM_STAMP(C, 1);
   C.gmres(du, bb, ax0);
   CGM_STAMP(C, 12);
@@ -1027,14 +1055,16 @@ __global__ __launch_bounds__(IPW * 16) __attribute__((amdgpu_waves_per_eu(1, 1))
     __syncthreads();
     C.template preamble<false>(a, c2);
     if (P.hook_out) store_im(P.hook_out, a);
-    C.lds_to_reg(a, C.S.Fh);
-    C.reg_to_row(P.Fh, P.Lg, a);
+    if (!C.fh_hbm()) {  // (with fh_hbm the preamble has already stored the row)
+      C.lds_to_reg(a, C.S.Fh);
+      C.reg_to_row(P.Fh, P.Lg, a);
+    }
     if (C.valid && C.r < M::NX) P.xdxh[size_t(C.b) * M::NX + C.r] = C.S.xh[C.r * IPW + C.inst];
     return;
   }
   // AX / GMRES: state left by PREPARE
   C.load_common(P.U);
-  C.load_row_to_lds(C.S.Fh, P.Fh);
+  if (!C.fh_hbm()) C.load_row_to_lds(C.S.Fh, P.Fh);
   if (C.valid && C.r < M::NX) C.S.xh[C.r * IPW + C.inst] = P.xdxh[size_t(C.b) * M::NX + C.r];
   for (int q = C.r; q < P.Hp; q += 16) C.S.H[C.inst * P.Hp + q] = T(0);
   load_im(a, P.hook_in0);
