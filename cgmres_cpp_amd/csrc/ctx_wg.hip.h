@@ -85,7 +85,7 @@ struct CtxWg final : cgmres_hip_ctx {
                                 int(lds_bytes)));
     const int k1 = cfg.k_max + 1;
     ks_all = k1 * k1 + k1 + 3 * cfg.k_max;
-    P.B = cfg.batch, P.dv = cfg.dv, P.kmax = cfg.k_max, P.L = L, P.fh_hbm = fh_hbm;
+    P.B = cfg.batch, P.dv = cfg.dv, P.kmax = cfg.k_max, P.L = L, P.fh_hbm = fh_hbm, P.lds_bytes = int(lds_bytes);
     P.Lp = L | 1, P.Lg = (L + 15) / 16 * 16, P.Lv = 16 * maxm, P.Pp = (np * (cfg.dv + 1)) | 1, P.Hp = (k1 * k1) | 1;
     P.h = T(cfg.h), P.dt = T(cfg.dt), P.tol = T(cfg.tol);
     P.inv_h = T(1.0) / P.h;

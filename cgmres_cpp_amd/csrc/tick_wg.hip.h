@@ -37,7 +37,7 @@ enum WgMode { WG_TICK = 0, WG_HOOK_F = 1, WG_HOOK_PREPARE = 2, WG_HOOK_AX = 3, W
 
 template <class T>
 struct WgParams {
-  int B, dv, kmax, L, Lp, Lg, Lv, Pp, Hp, fh_hbm;  // fh_hbm: F(U,x+hf,t+h) is kept in HBM only (P.Fh), see WgLds
+  int B, dv, kmax, L, Lp, Lg, Lv, Pp, Hp, fh_hbm, lds_bytes;  // fh_hbm: F(U,x+hf,t+h) is kept in HBM only (P.Fh), see WgLds
    // Lp/Pp/Hp: odd LDS row pitches; Lg: global row pitch (multiple of 16);
                                         // Lv = 16*MAXM: pitch of the Krylov rows (pads kept zero, no guards)
   T h, dt, tol, inv_h, one_m_zh, dtau_h, dtau_0;
@@ -512,10 +512,9 @@ struct WgCtx {
 #pragma unroll
     for (int j = 0; j < NP; ++j) p[j] = S.p[i * P.Pp + dv * NP + j];
     M::dPhidx(l, xs, p);
-    // Two stages per loop trip with two register sets: the LDS operands of the next stage are in flight while this
-    // one computes.  One wave issues one instruction per ~4.4 cycles whatever it is (tools/ubench_issue.hip), so the
-    // loop is written for instruction count: moving pointers with immediate offsets, no branch inside a trip, and the
-    // look-ahead fetch is unconditional (below stage 0 it reads words of the preceding LDS arrays, never used).
+    // One wave issues one instruction per ~4.4 cycles whatever it is (tools/ubench_issue.hip), so the loop is written
+    // for instruction count: moving pointers with immediate offsets, no branch inside a trip, unconditional
+    // look-ahead fetches.
     constexpr int STEP = NSTG * IPW;
     struct Ops {
       T bw[NBW], o[NUL];
@@ -536,19 +535,44 @@ struct WgCtx {
 #pragma unroll
       for (int j = 0; j < NUL; ++j) po[j] = a.o[j] + dF[j] * sc;
     };
-    Ops A, B;
+    // Three register sets, three stages per trip: the operands of stage t-2 are requested while stage t computes
+    // (two LDS latencies of slack).  q/o sit on stage s-4 of the trip that starts with stage s: every access is
+    // pointer + non-negative immediate.  Below stage 0 the look-ahead reads words of the preceding LDS arrays
+    // (at most 2 stages = 2*STEP scalars, less than one row array), never used.  LDS accesses outside the
+    // workgroup's allocation FAULT on this platform (aperture violation): -DCGM_DEBUG_LDS checks every address here.
+#ifdef CGM_DEBUG_LDS
+    auto chk = [&](const void* ptr, int what) {
+      const long off = static_cast<const char*>(ptr) - reinterpret_cast<const char*>(S.U);
+      if (off < 0 || off + 16 > long(P.lds_bytes)) printf("LDS OOB what=%d off=%ld tid=%d dv=%d\n", what, off, tid, dv);
+    };
+#else
+    auto chk = [&](const void*, int) {};
+#endif
+    auto fetch3 = [&](Ops& a, const T* pr3, const T* po3) {
+      chk(pr3, 1), chk(pr3 + (NBW / 2 - 1) * 2 * IPW, 2), chk(po3, 3);
+      fetch(a, pr3, po3);
+    };
+    auto stage3 = [&](const Ops& a, T* po3) {
+      chk(po3, 4);
+      stage(a, po3);
+    };
+    Ops A, B, C;
     int s = dv - 1;
-    const T* pr = S.R + 2 * i + (dv - 2) * STEP;  // the lower stage of the current pair (pair-interleaved, see coeff_item)
-    T* po = out + i * P.Lp + (dv - 2) * NU;
-    fetch(A, pr + STEP, po + NU);
-    for (; s >= 1; s -= 2) {
-      fetch(B, pr, po);
-      stage(A, po + NU);
-      fetch(A, pr - STEP, po - NU);
-      stage(B, po);
-      pr -= 2 * STEP, po -= 2 * NU;
+    const T* q = S.R + 2 * i + (dv - 5) * STEP;  // pair-interleaved coefficients, see coeff_item
+    T* o = out + i * P.Lp + (dv - 5) * NU;
+    fetch3(A, q + 4 * STEP, o + 4 * NU);  // stage dv-1
+    fetch3(B, q + 3 * STEP, o + 3 * NU);  // stage dv-2
+    for (; s >= 2; s -= 3) {
+      fetch3(C, q + 2 * STEP, o + 2 * NU);
+      stage3(A, o + 4 * NU);
+      fetch3(A, q + STEP, o + NU);
+      stage3(B, o + 3 * NU);
+      fetch3(B, q, o);
+      stage3(C, o + 2 * NU);
+      q -= 3 * STEP, o -= 3 * NU;
     }
-    if (s == 0) stage(A, po + NU);
+    if (s >= 0) stage3(A, o + 4 * NU);
+    if (s >= 1) stage3(B, o + 3 * NU);
   }
 
   // One complete sweep on the LDS table.  COLLECTIVE: every thread of the block must call it (two workgroup barriers
