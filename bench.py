@@ -26,7 +26,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MODEL, DV, KMAX = "pendulum", 50, 10
 DIM_X, DIM_U, DIM_P = 4, 3, 2
 # rocprofv3 PMC summary of this same command (tools/profile_bench.sh + tools/summarise_profile.py)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_v8_wg_bench_pmc.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_v9_wg_bench_pmc.json")
 
 
 def algorithmic_bytes(k, L=DIM_U * DV, scalar=8):
