@@ -7,17 +7,21 @@
 //     (quad_perm, quad_perm, row_half_mirror, row_mirror): every lane of the row ends with the
 //     bit-identical sum, so row-uniform branches (early exit, breakdown) never diverge inside a row.
 //   * a horizon sweep (F_func, cgmres.hpp:113-162) has three phases:
-//       1. state sweep  — serial in the stage index: one lane per instance (lanes 0..IPW-1 of wave 0),
-//                         x(s) and the reusable trig values go to the LDS stage table R;
+//       1. state sweep  — serial in the stage index, on wave 0: four lanes (one DPP quad) per instance for the
+//                         pendulum (PendulumDev::quad_stage), one lane per instance otherwise; x(s) and the
+//                         reusable trig values go to the LDS stage table R;
 //       2. coefficients — everything of the backward stage that does not involve the costate (dHdx and dHdu
-//                         are affine in it, models.hip.h) for ALL (stage, instance) pairs at once, by all threads;
-//       3. costate sweep — serial again, but only the short affine recurrence is left (pendulum: 14 fp64 ops
+//                         are affine in it, models.hip.h) for ALL (stage, instance) pairs at once; inside the
+//                         Arnoldi loop waves 1..3 do this chunk by chunk BEHIND the state sweep (f_eval);
+//       3. costate sweep — serial again, but only the short affine recurrence is left (pendulum: 12 fp64 ops
 //                         per stage instead of 46), fused with the costate part of dH/du.
 //     U, F(U,x+hf,t+h), the work vector, the stage table and ptau all sit in LDS (odd row pitches: conflict-free
-//     for the sweep lanes); there is no HBM access inside the stage loops.
+//     for the sweep lanes); there is no HBM access inside the stage loops.  (Long vectors: WgParams::fh_hbm.)
 //   * the Krylov basis V (IPW x (k_max+1) x L) does not fit in 160 KB of LDS at IPW = 16, it lives in
-//     HBM/L2 as instance-major rows (each row-load is one 128-byte segment per 16 lanes) and is
-//     streamed once per Gram-Schmidt step — exactly the traffic SURVEY.md §8(d) prices.
+//     HBM/L2 as zero-padded, pair-interleaved rows of 16*MAXM scalars (16-byte accesses, no guards) and is
+//     streamed once per Gram-Schmidt step through a register ring — the traffic SURVEY.md §8(d) prices.
+//   * the serial phases run on ONE wave, which issues one instruction of any kind per ~4.4 cycles
+//     (tools/ubench_issue.hip): the stage loops are written for instruction count.
 //   * instances never exchange data: the only synchronisation is the workgroup barrier between phases.
 // Statement order inside each instance follows cgmres.hpp:78-175 / gmres.hpp:28-112; what differs from the
 // reference is the association order of sums (16 partial sums + butterfly; affine regrouping of the costate step).
