@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Soak (dev tool): long closed loops of every built-in model on the device; checks that everything stays finite,
+that the early-exit statistics look sane and prints the wall time.  python tools/soak.py [ticks]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import cgmres_cpp_amd as cg
+from cgmres_cpp_amd import scenarios
+ticks = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
+for model, B, dv, km, dtype in [("pendulum", 4096, 50, 10, "f64"), ("msd", 4096, 50, 10, "f64"), ("semiactive", 4096, 50, 10, "f64"),
+                                ("pendulum", 1000, 100, 20, "f32"), ("pendulum", 77, 25, 5, "f64")]:
+    x0, u0, p = scenarios.batch(model, B)
+    c = cg.CgmresBatch(model, batch=B, dv=dv, k_max=km, dtype=dtype)  # shipped tol (1e-6): early exits live
+    if p.shape[1]: c.set_ptau_repeat(p)
+    c.init_u0(u0); c.init_u0_newton(u0, x0, p, 10)
+    npdt = np.float64 if dtype == "f64" else np.float32
+    xd = c.device_buffer(x0.shape, npdt).upload(x0.astype(npdt)); ud = c.device_buffer(u0.shape, npdt)
+    t0 = time.time(); c.closed_loop_device(xd, ud, ticks); c.synchronize(); dt = time.time() - t0
+    x, u = xd.download(), ud.download()
+    n_ax, reason = c.get_status()
+    print(f"{model:10s} B={B} dv={dv} k={km} {dtype}: {ticks} ticks in {dt:.2f}s, finite={np.isfinite(x).all() and np.isfinite(u).all()}, "
+          f"max|x|={np.abs(x).max():.3g} max|u|={np.abs(u).max():.3g}, mean Arnoldi={n_ax.mean():.2f}, exits={np.bincount(reason, minlength=4).tolist()}", flush=True)
+    assert np.isfinite(x).all() and np.isfinite(u).all()
+    c.close()
