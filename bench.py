@@ -6,7 +6,8 @@ example's forward-Euler plant, everything resident in HBM.
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 
-One "step" = one control tick of the whole per-GPU batch (one launch of the tick kernel).  Weak scaling:
+One "step" = one control tick of the whole per-GPU batch; the closed loop runs on the device and the tick kernel
+advances cgmres_cpp_amd.TICKS_PER_LAUNCH (10) consecutive ticks per launch.  Weak scaling:
 every rank owns `--batch` controllers; rank 0 draws the whole job's seeded inputs and the shards are
 scattered over RCCL (cgmres_cpp_amd/sharding.py); there is no collective inside the timed region because
 controller instances are independent.  Prints ONE JSON line on rank 0.
@@ -26,7 +27,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MODEL, DV, KMAX = "pendulum", 50, 10
 DIM_X, DIM_U, DIM_P = 4, 3, 2
 # rocprofv3 PMC summary of this same command (tools/profile_bench.sh + tools/summarise_profile.py)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_v9_wg_bench_pmc.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_v10_wg_bench_pmc.json")
 
 
 def algorithmic_bytes(k, L=DIM_U * DV, scalar=8):
@@ -59,14 +60,14 @@ def cpu_baseline(batch, tol, warm, seconds_budget):
                       f"mean Arnoldi iterations last tick {ks.mean():.2f}"}
 
 
-def measured_traffic(kernel_variant):
+def measured_traffic(kernel_variant, ticks_per_launch):
     """HBM bytes per launch from the committed PMC passes of this command (null when none matches)."""
     try:
         s = json.load(open(PMC_SUMMARY))
     except OSError:
         return None, None
     want = "tick_wg_kernel" if kernel_variant == 2 else "tick_lane_kernel"
-    if want not in s.get("kernel", ""):
+    if want not in s.get("kernel", "") or s.get("ticks_per_launch", 1) != ticks_per_launch:
         return None, None
     return s["hbm_bytes_per_launch"], os.path.relpath(PMC_SUMMARY, ROOT)
 
@@ -155,11 +156,16 @@ def main():
         sys.exit("non-finite control output: refusing to report a number")
     value = B * world * args.steps / wall
     ms_per_step = wall * 1e3 / args.steps
-    launch_ms = kernel_ms / args.steps
-    bytes_per_launch = float(sum(algorithmic_bytes(int(k)) for k in n_ax)) if args.tol > 0 else \
+    # one launch of the wg mapping = TICKS_PER_LAUNCH consecutive ticks of the batch (the lane mapping: one tick)
+    tpl = cg.TICKS_PER_LAUNCH if resolved["variant"] == 2 else 1
+    n_launches = -(-args.steps // tpl)
+    launch_ms = kernel_ms / n_launches
+    bytes_per_tick = float(sum(algorithmic_bytes(int(k)) for k in n_ax)) if args.tol > 0 else \
         float(B * algorithmic_bytes(KMAX))
+    bytes_per_launch = bytes_per_tick * args.steps / n_launches
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
-    traffic, traffic_src = measured_traffic(resolved["variant"]) if B == 4096 and args.tol == 0.0 else (None, None)
+    traffic, traffic_src = measured_traffic(resolved["variant"], args.steps / n_launches) \
+        if B == 4096 and args.tol == 0.0 else (None, None)
 
     ref_mode = None
     if not args.no_ref_mode and args.tol == 0.0:
@@ -180,8 +186,8 @@ def main():
                    "inputs": "splitmix64(12345) perturbed x0/targets, Newton-initialised U0 (SURVEY.md §8d)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": f"{kernel_name} (one launch per control step)", "launch_ms": launch_ms,
-                     "algorithmic_bytes_per_launch": bytes_per_launch},
+                     "kernel": f"{kernel_name} ({tpl} control step(s) of the batch per launch)", "launch_ms": launch_ms,
+                     "ticks_per_launch": args.steps / n_launches, "algorithmic_bytes_per_launch": bytes_per_launch},
     }
     if ref_mode:
         out["reference_mode"] = ref_mode

@@ -20,6 +20,7 @@ MODEL_IDS = {"pendulum": PENDULUM, "arm_type_inverted_pendulum": PENDULUM, "msd"
 F64, F32 = 0, 1
 EXIT_NATURAL, EXIT_CONVERGED, EXIT_SMALL_RESIDUAL, EXIT_BREAKDOWN = 0, 1, 2, 3
 ABI_VERSION = 1
+TICKS_PER_LAUNCH = 10  # CGMRES_HIP_TICKS_PER_LAUNCH: closed_loop_device fuses this many ticks per launch (wg mapping)
 
 # every symbol include/cgmres_hip.h declares (tests/test_capi_symbols.py checks header == this == library)
 SYMBOLS = [

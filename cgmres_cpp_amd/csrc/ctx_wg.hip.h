@@ -164,16 +164,22 @@ struct CtxWg final : cgmres_hip_ctx {
     return 0;
   }
 
-  int launch_tick(T* u_out, const T* x_in, T* x_next) {
+  // n consecutive ticks in one launch (n > 1 needs the on-device plant: x_next != nullptr)
+  int launch_ticks(T* u_out, const T* x_in, T* x_next, int n) {
     P.mode = WG_TICK;
     P.x_in = x_in, P.u_out = u_out, P.x_next = x_next;
-    P.dtau_h = dtau_of(t + P.h);  // cgmres.hpp:88
-    P.dtau_0 = dtau_of(t);        // cgmres.hpp:91
+    P.n_ticks = n;
+    for (int k = 0; k < n; ++k) {
+      P.dtau_tab[2 * k] = dtau_of(t + P.h);  // cgmres.hpp:88
+      P.dtau_tab[2 * k + 1] = dtau_of(t);    // cgmres.hpp:91
+      t = t + P.dt;                          // cgmres.hpp:107
+    }
+    P.dtau_h = P.dtau_tab[0], P.dtau_0 = P.dtau_tab[1];
     k_tick<<<grid(), block(), lds_bytes, stream>>>(P);
     HIP_TRY(hipGetLastError());
-    t = t + P.dt;  // cgmres.hpp:107
     return 0;
   }
+  int launch_tick(T* u_out, const T* x_in, T* x_next) { return launch_ticks(u_out, x_in, x_next, 1); }
   int control_device(void* u, const void* x, void* x_next) override {
     HIP_TRY(hipSetDevice(cfg.device));
     if (!u || !x) return fail(CGMRES_HIP_EINVAL, "control: null pointer");
@@ -191,8 +197,10 @@ struct CtxWg final : cgmres_hip_ctx {
   int closed_loop(void* x, void* u, int n_ticks) override {
     HIP_TRY(hipSetDevice(cfg.device));
     if (!u || !x) return fail(CGMRES_HIP_EINVAL, "closed_loop: null pointer");
-    for (int i = 0; i < n_ticks; ++i)
-      if (int rc = launch_tick(static_cast<T*>(u), static_cast<const T*>(x), static_cast<T*>(x))) return rc;
+    for (int i = 0; i < n_ticks; i += CGM_FUSE_MAX) {
+      const int n = n_ticks - i < CGM_FUSE_MAX ? n_ticks - i : CGM_FUSE_MAX;
+      if (int rc = launch_ticks(static_cast<T*>(u), static_cast<const T*>(x), static_cast<T*>(x), n)) return rc;
+    }
     return 0;
   }
 

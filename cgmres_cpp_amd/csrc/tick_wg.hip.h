@@ -37,6 +37,9 @@
 
 namespace cgm {
 
+constexpr int CGM_FUSE_MAX = CGMRES_HIP_TICKS_PER_LAUNCH;
+static_assert(CGM_FUSE_MAX == 10, "WgParams::dtau_tab");
+
 enum WgMode { WG_TICK = 0, WG_HOOK_F = 1, WG_HOOK_PREPARE = 2, WG_HOOK_AX = 3, WG_HOOK_GMRES = 4 };
 
 template <class T>
@@ -45,6 +48,11 @@ struct WgParams {
    // Lp/Pp/Hp: odd LDS row pitches; Lg: global row pitch (multiple of 16);
                                         // Lv = 16*MAXM: pitch of the Krylov rows (pads kept zero, no guards)
   T h, dt, tol, inv_h, one_m_zh, dtau_h, dtau_0;
+  // closed loop on the device: up to CGM_FUSE_MAX consecutive ticks per launch, the controller state (U in LDS, dUdt
+  // in registers, x in LDS) carried from tick to tick without going through HBM; dtau_tab[2*k], [2*k+1] = the two
+  // horizon steps of tick k (cgmres.hpp:88,91), computed by the host exactly as for single launches
+  int n_ticks;
+  T dtau_tab[2 * 10];
   // instance-major HBM state
   T *U, *dUdt, *Fh, *V, *xdxh, *ptau;  // [B][Lg], [B][Lg], [B][Lg], [B][kmax+1][Lv], [B][NX], [B][NP*(dv+1)]
   T* kry;                              // [B][KS]: H (k1*k1 col-major) | rho (k1) | g (3*kmax)
@@ -133,6 +141,7 @@ struct WgCtx {
   int tid, inst, r, b;  // b = global instance of this thread's row
   bool valid;           // row has a real instance
   bool sweep_lane;      // this thread runs the serial sweeps (for instance `tid`)
+  T dtau_h, dtau_0;     // horizon steps of the current tick: F(., t+h) and F(., t)
   int bi;               // global instance of the sweep lane
   typename M::Math mc;  // per-thread math context (pinned sin/cos constants); A/B: keeping it live for the whole
                         // kernel is 13 us/tick FASTER than re-creating it inside every sweep
@@ -142,6 +151,7 @@ struct WgCtx {
     valid = b < P.B;
     bi = blockIdx.x * IPW + tid;
     sweep_lane = tid < IPW && bi < P.B;
+    dtau_h = P.dtau_h, dtau_0 = P.dtau_0;
     mc.init();
     CGM_STAMP(*this, -1);
   }
@@ -653,15 +663,15 @@ struct WgCtx {
       T* tab0 = P.scr + size_t(blockIdx.x) * 2 * tab_n;
       T* tab1 = tab0 + tab_n;
       T* xT0 = S.xT, *xT1 = S.xT + M::NX * IPW, *xT2 = S.xT + 2 * M::NX * IPW;
-      sweep_state<false, false>(0, S.xh, P.dtau_h, S.R, xT0, false);
-      sweep_state<false, false>(64, S.xs, P.dtau_0, tab0, xT1, false);
-      if (WITH_AX0) sweep_state<true, false>(128, S.xh, P.dtau_h, tab1, xT2, false);
+      sweep_state<false, false>(0, S.xh, dtau_h, S.R, xT0, false);
+      sweep_state<false, false>(64, S.xs, dtau_0, tab0, xT1, false);
+      if (WITH_AX0) sweep_state<true, false>(128, S.xh, dtau_h, tab1, xT2, false);
       __threadfence_block();
       __syncthreads();  // drains vmcnt: the HBM tables are complete and visible to the other waves of this CU
       CGM_STAMP(*this, 4);
-      sweep_coeffs<false, F_PLAIN>(P.dtau_h, S.R, S.Fh, false);  // (S.Fh is S.W itself when fh_hbm)
+      sweep_coeffs<false, F_PLAIN>(dtau_h, S.R, S.Fh, false);  // (S.Fh is S.W itself when fh_hbm)
       __syncthreads();
-      sweep_costate<F_PLAIN>(P.dtau_h, xT0, S.Fh, false);
+      sweep_costate<F_PLAIN>(dtau_h, xT0, S.Fh, false);
       __syncthreads();
       if (fh_hbm()) {
         // Fh went through W: move it to its HBM row and put the direction of A*x0 back (its first copy served the
@@ -675,29 +685,29 @@ struct WgCtx {
         __syncthreads();
       }
       if (WITH_AX0) {
-        sweep_coeffs<true, F_AX>(P.dtau_h, tab1, S.W, false);
+        sweep_coeffs<true, F_AX>(dtau_h, tab1, S.W, false);
         __syncthreads();
-        sweep_costate<F_AX>(P.dtau_h, xT2, S.W, false);
+        sweep_costate<F_AX>(dtau_h, xT2, S.W, false);
         __syncthreads();
         lds_to_reg(ax0, S.W);
         __syncthreads();
       }
-      sweep_coeffs<false, F_RHS>(P.dtau_0, tab0, S.W, false);
+      sweep_coeffs<false, F_RHS>(dtau_0, tab0, S.W, false);
       __syncthreads();
-      sweep_costate<F_RHS>(P.dtau_0, xT1, S.W, false);
+      sweep_costate<F_RHS>(dtau_0, xT1, S.W, false);
       __syncthreads();
       lds_to_reg(bb, S.W);
       __syncthreads();
     } else {
-      f_eval<false, F_PLAIN>(S.xh, P.dtau_h, S.Fh, false);
+      f_eval<false, F_PLAIN>(S.xh, dtau_h, S.Fh, false);
       __syncthreads();
       if (WITH_AX0) {
-        f_eval<true, F_AX>(S.xh, P.dtau_h, S.W, false);
+        f_eval<true, F_AX>(S.xh, dtau_h, S.W, false);
         __syncthreads();
         lds_to_reg(ax0, S.W);
         __syncthreads();
       }
-      f_eval<false, F_RHS>(S.xs, P.dtau_0, S.W, false);
+      f_eval<false, F_RHS>(S.xs, dtau_0, S.W, false);
       __syncthreads();
       lds_to_reg(bb, S.W);
       __syncthreads();
@@ -707,7 +717,7 @@ struct WgCtx {
   template <class After>
   __device__ __forceinline__ void ax(bool only_active, After&& after_sweep) {
     CGM_STAMP(*this, 3);
-    f_eval<true, F_AX>(S.xh, P.dtau_h, S.W, only_active, after_sweep);
+    f_eval<true, F_AX>(S.xh, dtau_h, S.W, only_active, after_sweep);
     __syncthreads();
     CGM_STAMP(*this, 6);
   }
@@ -999,40 +1009,53 @@ __global__ __launch_bounds__(IPW * 16) __attribute__((amdgpu_waves_per_eu(1, 1))
   T du[MAXM], bb[MAXM];
   C.load_common(P.U);
   C.load_row_to_reg(du, P.dUdt, P.Lg);
-  // H region zeroed so the exported Hessenberg has no stale entries
-  for (int q = C.r; q < P.Hp; q += 16) C.S.H[C.inst * P.Hp + q] = T(0);
-  __syncthreads();
-  CGM_STAMP(C, 0);
-  C.publish_direction(du);  // direction of the first mat-vec: x0 = dUdt (warm start, cgmres.hpp:99)
-  T ax0[MAXM];
-  C.template preamble<true>(bb, ax0, du);  // Fh in LDS (or HBM); b and A*dUdt in registers
-  CGM_STAMP(C, 1);
-  C.gmres(du, bb, ax0);
-  CGM_STAMP(C, 12);
-  // U += dUdt*dt, u = U[0:dim_u]  (cgmres.hpp:102-109)
-  T un[MAXM];
-  C.lds_to_reg(un, C.S.U);
-#pragma unroll
-  for (int m = 0; m < MAXM; ++m) un[m] = un[m] + du[m] * P.dt;
-  C.reg_to_row(P.U, P.Lg, un);
-  C.reg_to_row(P.dUdt, P.Lg, du);
-  if (C.valid && C.r < M::NU) {
-    P.u_out[size_t(C.b) * M::NU + C.r] = un[0];  // element e = r (m = 0) for r < NU <= 16
-    C.S.U[C.inst * P.Lp + C.r] = un[0];
-  }
-  C.store_status();
-  if (P.x_next) {  // plant step of the example main loop (<example>/main.cpp:71-73)
+  const int nt = P.n_ticks;
+  for (int tk = 0; tk < nt; ++tk) {
+    const bool last = tk + 1 == nt;
+    C.dtau_h = P.dtau_tab[2 * tk], C.dtau_0 = P.dtau_tab[2 * tk + 1];
+    // H region zeroed so the exported Hessenberg has no stale entries
+    for (int q = C.r; q < P.Hp; q += 16) C.S.H[C.inst * P.Hp + q] = T(0);
     __syncthreads();
-    if (C.sweep_lane) {
-      const int i = C.tid;
-      T x[M::NX], u[M::NU], f[M::NX], tr[M::NC > 0 ? M::NC : 1];
+    CGM_STAMP(C, 0);
+    C.publish_direction(du);  // direction of the first mat-vec: x0 = dUdt (warm start, cgmres.hpp:99)
+    T ax0[MAXM];
+    C.template preamble<true>(bb, ax0, du);  // Fh in LDS (or HBM); b and A*dUdt in registers
+    CGM_STAMP(C, 1);
+    C.gmres(du, bb, ax0);
+    CGM_STAMP(C, 12);
+    // U += dUdt*dt, u = U[0:dim_u]  (cgmres.hpp:102-109)
+    T un[MAXM];
+    C.lds_to_reg(un, C.S.U);
 #pragma unroll
-      for (int c = 0; c < M::NX; ++c) x[c] = C.S.xs[c * IPW + i];
+    for (int m = 0; m < MAXM; ++m) un[m] = un[m] + du[m] * P.dt;
+    if (last) {  // the controller state goes back to HBM with the last tick of the launch only
+      C.reg_to_row(P.U, P.Lg, un);
+      C.reg_to_row(P.dUdt, P.Lg, du);
+      if (C.valid && C.r < M::NU) P.u_out[size_t(C.b) * M::NU + C.r] = un[0];  // element e = r (m = 0), r < NU <= 16
+      C.store_status();
+    }
+    C.reg_to_lds(C.S.U, un);  // the plant step and the next tick read U from LDS
+    if (P.x_next) {  // plant step of the example main loop (<example>/main.cpp:71-73)
+      __syncthreads();
+      if (C.sweep_lane) {
+        const int i = C.tid;
+        T x[M::NX], u[M::NU], f[M::NX], tr[M::NC > 0 ? M::NC : 1];
 #pragma unroll
-      for (int j = 0; j < M::NU; ++j) u[j] = C.S.U[i * P.Lp + j];
-      M::dxdt(f, x, u, tr, C.mc);
+        for (int c = 0; c < M::NX; ++c) x[c] = C.S.xs[c * IPW + i];
 #pragma unroll
-      for (int c = 0; c < M::NX; ++c) P.x_next[size_t(C.bi) * M::NX + c] = x[c] + f[c] * P.dt;
+        for (int j = 0; j < M::NU; ++j) u[j] = C.S.U[i * P.Lp + j];
+        M::dxdt(f, x, u, tr, C.mc);
+#pragma unroll
+        for (int c = 0; c < M::NX; ++c) {
+          const T xn = x[c] + f[c] * P.dt;
+          if (last) P.x_next[size_t(C.bi) * M::NX + c] = xn;
+          C.S.xs[c * IPW + i] = xn;
+        }
+      }
+    }
+    if (!last) {
+      if (C.r == 0) C.S.flag[C.inst] = 0, C.S.reason[C.inst] = 0, C.S.nax[C.inst] = 0, C.S.ksolve[C.inst] = 0;
+      __syncthreads();  // U, x and the cleared status words are in place for the next tick
     }
   }
   CGM_STAMP(C, 13);

@@ -35,9 +35,13 @@ class MultipleController:
 
     def closed_loop_device(self, xs, us, n_ticks):
         """n_ticks of every member's closed loop; ticks of different members interleave on their streams."""
-        for _ in range(n_ticks):
+        from . import TICKS_PER_LAUNCH  # one launch advances this many ticks of a member: interleave launch-wise
+        done = 0
+        while done < n_ticks:
+            n = min(TICKS_PER_LAUNCH, n_ticks - done)
             for m, x, u in zip(self.members, xs, us):
-                m.closed_loop_device(x, u, 1)
+                m.closed_loop_device(x, u, n)
+            done += n
 
     def synchronize(self):
         for m in self.members:

@@ -59,6 +59,10 @@ enum {
   CGMRES_HIP_EXIT_BREAKDOWN = 3       /* |h(k+1,k)| < DBL_EPSILON, dUdt untouched  gmres.hpp:63-65 */
 };
 
+/* cgmres_hip_closed_loop_device advances up to this many consecutive ticks per kernel launch (the controller
+ * state stays on chip between them); a tool that divides kernel time by ticks needs the number. */
+#define CGMRES_HIP_TICKS_PER_LAUNCH 10
+
 /* Run-time counterpart of the `static constexpr` block of a reference Model (e.g.
  * arm_type_inverted_pendulum/model.hpp:7-35), which Cgmres re-exports (cgmres.hpp:179-188). */
 typedef struct cgmres_hip_config {
