@@ -1,20 +1,33 @@
 #!/usr/bin/env python3
-"""Headline benchmark: C/GMRES control steps/s for a batch of arm_type_inverted_pendulum controllers
-(BASELINE.json: batch 4096 per GPU, N = dv = 50 horizon stages, k_max = 10, fp64), closed loop with the
-example's forward-Euler plant, everything resident in HBM.
+"""Headline benchmark: C/GMRES control steps/s for a batch of 4096 arm_type_inverted_pendulum controllers
+(BASELINE.json: N = dv = 50 horizon stages, k_max = 10, fp64), closed loop with the example's forward-Euler
+plant, everything resident in HBM.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 
-One "step" = one control tick of the whole per-GPU batch; the closed loop runs on the device and the tick kernel
-advances cgmres_cpp_amd.TICKS_PER_LAUNCH (10) consecutive ticks per launch.  Weak scaling:
-every rank owns `--batch` controllers; rank 0 draws the whole job's seeded inputs and the shards are
-scattered over RCCL (cgmres_cpp_amd/sharding.py); there is no collective inside the timed region because
-controller instances are independent.  Prints ONE JSON line on rank 0.
+One "step" = one control tick of the whole batch; the closed loop runs on the device and the tick kernel advances
+cgmres_cpp_amd.TICKS_PER_LAUNCH (10) consecutive ticks per launch.
+
+Scaling: the metric is a FIXED batch of 4096 controllers at 1/2/4/8 GPUs, so `value` is STRONG scaling — the 4096
+instances are split into contiguous shards (cgmres_cpp_amd.sharding.shard_bounds), one process per GPU; rank 0
+draws the seeded job and the shards go out once over RCCL; there is no collective inside the timed region
+(instances are independent).  For N > 1 the weak-scaling figure (4096 controllers per GPU) is measured in the same
+run and reported under "weak_scaling".
+
+The timed region (exactly K steps, barrier + synchronize on both sides, max over ranks) is repeated --reps times
+back to back on the continuing closed loop; `value`/`ms_per_step` are the MEDIAN repetition.
+
+Parity gate: before the line is printed, a spread sample of the instances this process just timed is checked against
+the oracle (oracle/liboracle.so, the checker — never the thing measured): free-running over the warm-up ticks
+(<= 100 ticks: 1e-9 on u and x), and — from the controller/plant state left by the timed
+region — 11 further ticks (one full fused launch + a launch boundary) teacher-forced from that state, 1e-9.
+On mismatch the script exits without a value.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -24,10 +37,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-MODEL, DV, KMAX = "pendulum", 50, 10
+MODEL, MODEL_ID, DV, KMAX = "pendulum", 0, 50, 10
 DIM_X, DIM_U, DIM_P = 4, 3, 2
-# rocprofv3 PMC summary of this same command (tools/profile_bench.sh + tools/summarise_profile.py)
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_v10_wg_bench_pmc.json")
+GLOBAL_BATCH = 4096
+# rocprofv3 PMC summary of this same command (tools/profile_bench.sh + tools/summarise_profile.py), newest first
+PMC_SUMMARIES = [os.path.join(ROOT, "profiles", n) for n in ("r02_wg_bench_pmc.json", "r01_v10_wg_bench_pmc.json")]
+ISSUE_MODEL = os.path.join(ROOT, "profiles", "r02_issue_model.json")
 
 
 def algorithmic_bytes(k, L=DIM_U * DV, scalar=8):
@@ -37,39 +52,114 @@ def algorithmic_bytes(k, L=DIM_U * DV, scalar=8):
 
 
 def cpu_baseline(batch, tol, warm, seconds_budget):
-    """The oracle (CPU restatement, bit-exact with the reference) on this host's cores: same seeded inputs,
-    closed loop, instances statically partitioned over all available threads."""
+    """The oracle (CPU restatement, bit-exact with the reference) on this host's cores: same seeded inputs, closed
+    loop.  Two legs: all hardware threads available to the process on the whole batch, and ONE
+    thread on the first 256 instances of the same batch."""
     from oracle import orc
     if not os.path.exists(orc.ORACLE_SO):
         orc.build(ref=False)
     threads = len(os.sched_getaffinity(0))
     x0, u0, p = orc.batch_scenario(orc.PENDULUM, batch)
-    ctrls = []
-    for i in range(batch):
-        c = orc.Controller(orc.PENDULUM, DV, KMAX, tol)
-        orc.start_controller(c, x0[i], u0[i], p[i])
-        ctrls.append(c)
-    secs_w, _, x = orc.run_closed_loop(ctrls, x0, warm, threads)
-    # size the timed part from the warm-up rate so the leg stays within its budget
-    ticks = int(max(5, min(200, seconds_budget / max(secs_w / warm, 1e-6))))
-    secs, _, _ = orc.run_closed_loop(ctrls, x, ticks, threads)
-    ks = np.array([c.last_solve()[0] for c in ctrls])
-    return {"value": batch * ticks / secs, "unit": "control steps/s", "cores": threads, "kind": "port",
+
+    def leg(n_inst, nthreads, budget):
+        ctrls = []
+        for i in range(n_inst):
+            c = orc.Controller(orc.PENDULUM, DV, KMAX, tol)
+            orc.start_controller(c, x0[i], u0[i], p[i])
+            ctrls.append(c)
+        secs_w, _, x = orc.run_closed_loop(ctrls, x0[:n_inst], warm, nthreads)
+        # size the timed part from the warm-up rate so the leg stays within its budget
+        ticks = int(max(5, min(200, budget / max(secs_w / warm, 1e-6))))
+        secs, _, _ = orc.run_closed_loop(ctrls, x, ticks, nthreads)
+        ks = np.array([c.last_solve()[0] for c in ctrls])
+        return n_inst * ticks / secs, ticks, float(ks.mean())
+
+    v_all, t_all, k_all = leg(batch, threads, seconds_budget)
+    n1 = min(256, batch)
+    v_one, t_one, _ = leg(n1, 1, seconds_budget)
+    return {"value": v_all, "unit": "control steps/s", "cores": threads, "kind": "port",
             "sample": f"oracle/liboracle.so (CPU restatement, bit-exact vs reference), {batch} controllers x "
-                      f"{ticks} closed-loop ticks after {warm} warm-up ticks, tol={tol:g}, {threads} std::threads, "
-                      f"mean Arnoldi iterations last tick {ks.mean():.2f}"}
+                      f"{t_all} closed-loop ticks after {warm} warm-up ticks, tol={tol:g}, {threads} std::threads, "
+                      f"mean Arnoldi iterations last tick {k_all:.2f}",
+            "one_thread": {"value": v_one, "unit": "control steps/s", "cores": 1,
+                           "sample": f"first {n1} controllers of the same batch x {t_one} ticks after {warm} "
+                                     f"warm-up ticks, 1 thread"}}
 
 
-def measured_traffic(kernel_variant, ticks_per_launch):
-    """HBM bytes per launch from the committed PMC passes of this command (null when none matches)."""
-    try:
-        s = json.load(open(PMC_SUMMARY))
-    except OSError:
+def committed_traffic(kernel_variant, ticks_per_launch, batch):
+    """HBM bytes per launch from the COMMITTED rocprofv3 PMC passes of this command (not measured in this run)."""
+    if kernel_variant != 2 or batch != GLOBAL_BATCH:
         return None, None
-    want = "tick_wg_kernel" if kernel_variant == 2 else "tick_lane_kernel"
-    if want not in s.get("kernel", "") or s.get("ticks_per_launch", 1) != ticks_per_launch:
-        return None, None
-    return s["hbm_bytes_per_launch"], os.path.relpath(PMC_SUMMARY, ROOT)
+    for path in PMC_SUMMARIES:
+        try:
+            s = json.load(open(path))
+        except OSError:
+            continue
+        if "tick_wg_kernel" in s.get("kernel", "") and s.get("ticks_per_launch", 1) == ticks_per_launch:
+            return s["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+    return None, None
+
+
+class ParityError(RuntimeError):
+    pass
+
+
+def sample_of(B, n):
+    step = max(1, B // n)
+    s = list(range(0, B, step))[:n]
+    for extra in (B - 1, 15, 16):
+        if 0 <= extra < B and extra not in s:
+            s.append(extra)
+    return sorted(s)
+
+
+class OracleSample:
+    """Checker for a spread sample of this rank's instances (oracle = test infrastructure, used as the checker only)."""
+
+    def __init__(self, tol, x0, u0, p, n):
+        from oracle import orc
+        if not os.path.exists(orc.ORACLE_SO):
+            orc.build(ref=False)
+        self.orc = orc
+        self.idx = sample_of(len(x0), n)
+        self.x = [x0[i].copy() for i in self.idx]
+        self.ctrls = []
+        for i in self.idx:
+            c = orc.Controller(orc.PENDULUM, DV, KMAX, tol)
+            orc.start_controller(c, x0[i], u0[i], p[i])
+            self.ctrls.append(c)
+        self.u = [None] * len(self.idx)
+
+    def advance(self, ticks):
+        for j, c in enumerate(self.ctrls):
+            for _ in range(ticks):
+                u = c.control(self.x[j])
+                self.x[j] = self.x[j] + c.plant(self.x[j], u) * c.dt
+                self.u[j] = u
+
+    def adopt(self, t, U, dUdt, x):
+        """Teacher forcing: take over the device's controller and plant state."""
+        for j, i in enumerate(self.idx):
+            self.ctrls[j].set_state(t, U[i], dUdt[i])
+            self.x[j] = x[i].copy()
+
+    def compare(self, what, x, u, n_ax, tol_u, strict_counts):
+        """max error of u and x over the sample; Arnoldi counts must be equal (in early-exit mode a differing count
+        is reported instead: the exit test can sit within rounding of tol)"""
+        worst = 0.0
+        self.flips = 0
+        for j, i in enumerate(self.idx):
+            du = float(np.max(np.abs(u[i] - self.u[j])))
+            dx = float(np.max(np.abs(x[i] - self.x[j])))
+            worst = max(worst, du, dx)
+            if not (du <= tol_u and dx <= tol_u):
+                raise ParityError(f"{what}: instance {i}: |du| = {du:.3e}, |dx| = {dx:.3e} > {tol_u:g}")
+            k_o = self.ctrls[j].last_solve()[0]
+            if n_ax[i] != k_o:
+                if strict_counts:
+                    raise ParityError(f"{what}: instance {i}: Arnoldi count {n_ax[i]} vs oracle {k_o}")
+                self.flips += 1
+        return worst
 
 
 def main():
@@ -77,14 +167,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--batch", type=int, default=4096, help="controllers per GPU")
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed K-step region (median reported)")
+    ap.add_argument("--batch", type=int, default=GLOBAL_BATCH, help="GLOBAL batch (split over the GPUs)")
     ap.add_argument("--tol", type=float, default=0.0,
                     help="0 = fixed-k mode (always k_max Arnoldi iterations, deterministic work; headline); "
                          "1e-6 = the reference's early-exit mode")
     ap.add_argument("--variant", type=int, default=0, help="kernel mapping: 0 default, 1 lane, 2 wg")
-    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall budget of the timed CPU-baseline part")
+    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall budget of each timed CPU-baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ref-mode", action="store_true", help="skip the secondary tol=1e-6 measurement")
+    ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the secondary weak-scaling measurement")
+    ap.add_argument("--check-sample", type=int, default=48, help="instances per rank checked against the oracle")
     args = ap.parse_args()
 
     import torch
@@ -92,13 +185,14 @@ def main():
 
     import cgmres_cpp_amd as cg
     from cgmres_cpp_amd import scenarios
-    from cgmres_cpp_amd.sharding import scatter_rows
+    from cgmres_cpp_amd.sharding import scatter_rows, shard_bounds
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1 and args.gpus > 1:
-        sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if world != args.gpus:
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE = {world}: launch with torch.distributed.run "
+                 f"--nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: there is no CPU path")
     torch.cuda.set_device(local)
@@ -106,21 +200,25 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
-
-    B = args.batch
-    # ---- inputs: rank 0 draws the whole job (seeded), shards go out over RCCL (the only exchange) ------
-    full = scenarios.batch(MODEL, B * world) if rank == 0 else (None, None, None)
-    x_d = scatter_rows(full[0], B * world, DIM_X, world, rank, dev, dist)
-    u0_d = scatter_rows(full[1], B * world, DIM_U, world, rank, dev, dist)
-    p_d = scatter_rows(full[2], B * world, DIM_P, world, rank, dev, dist)
-    torch.cuda.synchronize()
-    x0_h, u0_h, p_h = x_d.cpu().numpy(), u0_d.cpu().numpy(), p_d.cpu().numpy()
-    assert x0_h.shape == (B, DIM_X)
+        assert dist.get_world_size() == args.gpus
 
     stream = torch.cuda.current_stream().cuda_stream
     resolved = {}
 
-    def run(tol, steps, warmup):
+    def shard_inputs(n_global):
+        """rank 0 draws the whole job (seeded); the shards go out over RCCL — the only exchange of the job"""
+        full = scenarios.batch(MODEL, n_global) if rank == 0 else (None, None, None)
+        parts = [scatter_rows(full[k], n_global, w, world, rank, dev, dist) for k, w in enumerate((DIM_X, DIM_U, DIM_P))]
+        torch.cuda.synchronize()
+        lo, hi = shard_bounds(n_global, world, rank)
+        out = [t.cpu().numpy() for t in parts]
+        assert out[0].shape == (hi - lo, DIM_X)
+        return out
+
+    def measure(inputs, tol, steps, warmup, reps, check):
+        """Closed loop of this rank's shard: warm-up, then `reps` timed regions of exactly `steps` ticks."""
+        x0_h, u0_h, p_h = inputs
+        B = len(x0_h)
         ctrl = cg.CgmresBatch(MODEL, batch=B, dv=DV, k_max=KMAX, tol=tol, device=local, stream=stream,
                               variant=args.variant)
         resolved["variant"] = ctrl.variant
@@ -129,70 +227,132 @@ def main():
         ctrl.init_u0_newton(u0_h, x0_h, p_h, 10)
         x = torch.from_numpy(x0_h).to(dev)
         u = torch.zeros(B, DIM_U, dtype=torch.float64, device=dev)
+        chk = OracleSample(tol, x0_h, u0_h, p_h, check) if check else None
+        parity = {}
         ctrl.closed_loop_device(x, u, warmup)
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ctrl.timer_start()
-        ctrl.closed_loop_device(x, u, steps)
-        kernel_ms = ctrl.timer_stop()  # HIP events on the launch stream, around exactly the K launches
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        wall = time.perf_counter() - t0
-        n_ax, reason = ctrl.get_status()
+        err = None
+        try:
+            if chk and 0 < warmup <= 100:
+                chk.advance(warmup)
+                parity["warmup_free_running_max_err"] = chk.compare(
+                    f"free-running warm-up ({warmup} ticks)", x.cpu().numpy(), u.cpu().numpy(), ctrl.get_status()[0],
+                    1e-9, tol == 0.0)
+                parity["arnoldi_count_flips"] = chk.flips
+        except ParityError as e:
+            err = str(e)
+        walls, kernels = [], []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ctrl.timer_start()
+            ctrl.closed_loop_device(x, u, steps)
+            kernel_ms = ctrl.timer_stop()  # HIP events on the launch stream, around exactly the K-step launches
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - t0
+            tt = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            walls.append(tt[0].item()), kernels.append(tt[1].item())
+        n_ax, _ = ctrl.get_status()
         finite = bool(torch.isfinite(u).all().item()) and bool(torch.isfinite(x).all().item())
+        try:
+            if chk and err is None:
+                # the state the timed region left behind, continued on both sides: 11 ticks = a full fused launch,
+                # a launch boundary and a 1-tick launch (teacher-forced from the device's own state)
+                t_dev, U_dev, d_dev = ctrl.get_state()
+                chk.adopt(t_dev, U_dev, d_dev, x.cpu().numpy())
+                ctrl.closed_loop_device(x, u, 11)
+                torch.cuda.synchronize()
+                chk.advance(11)
+                parity["continuation_max_err"] = chk.compare(
+                    "11-tick continuation of the timed state", x.cpu().numpy(), u.cpu().numpy(), ctrl.get_status()[0],
+                    1e-9, tol == 0.0)
+                parity["arnoldi_count_flips"] = parity.get("arnoldi_count_flips", 0) + chk.flips
+                parity["instances_checked"] = len(chk.idx)
+        except ParityError as e:
+            err = str(e)
         ctrl.close()
-        tt = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=dev)
+        bad = torch.tensor([0 if (err is None and finite) else 1], dtype=torch.int32, device=dev)
         if world > 1:
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        return tt[0].item(), tt[1].item(), n_ax, finite
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if err is not None or not finite:
+            sys.stderr.write(f"[rank {rank}] PARITY FAILURE: {err or 'non-finite output'}\n")
+        if bad.item():
+            if world > 1:
+                dist.destroy_process_group()
+            sys.exit("parity check against the oracle failed: refusing to report a number")
+        med = statistics.median_low(walls)
+        return {"B": B, "wall": med, "kernel_ms": kernels[walls.index(med)], "walls": walls, "n_ax": n_ax,
+                "parity": parity}
 
-    wall, kernel_ms, n_ax, finite = run(args.tol, args.steps, args.warmup)
-    if not finite:
-        sys.exit("non-finite control output: refusing to report a number")
-    value = B * world * args.steps / wall
-    ms_per_step = wall * 1e3 / args.steps
+    n_check = args.check_sample if world == 1 else max(8, args.check_sample // world)
+    inputs = shard_inputs(args.batch)
+    m = measure(inputs, args.tol, args.steps, args.warmup, args.reps, n_check)
+    B = m["B"]
+    value = args.batch * args.steps / m["wall"]
+    ms_per_step = m["wall"] * 1e3 / args.steps
     # one launch of the wg mapping = TICKS_PER_LAUNCH consecutive ticks of the batch (the lane mapping: one tick)
     tpl = cg.TICKS_PER_LAUNCH if resolved["variant"] == 2 else 1
     n_launches = -(-args.steps // tpl)
-    launch_ms = kernel_ms / n_launches
-    bytes_per_tick = float(sum(algorithmic_bytes(int(k)) for k in n_ax)) if args.tol > 0 else \
+    launch_ms = m["kernel_ms"] / n_launches
+    bytes_per_tick = float(sum(algorithmic_bytes(int(k)) for k in m["n_ax"])) if args.tol > 0 else \
         float(B * algorithmic_bytes(KMAX))
     bytes_per_launch = bytes_per_tick * args.steps / n_launches
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
-    traffic, traffic_src = measured_traffic(resolved["variant"], args.steps / n_launches) \
-        if B == 4096 and args.tol == 0.0 else (None, None)
+    traffic, traffic_src = committed_traffic(resolved["variant"], args.steps / n_launches, B) \
+        if args.tol == 0.0 else (None, None)
 
     ref_mode = None
     if not args.no_ref_mode and args.tol == 0.0:
-        w2, _, n2, _ = run(1e-6, args.steps, args.warmup)
-        ref_mode = {"tol": 1e-6, "value": B * world * args.steps / w2, "ms_per_step": w2 * 1e3 / args.steps,
-                    "mean_arnoldi_last_tick": float(np.mean(n2))}
+        m2 = measure(inputs, 1e-6, args.steps, args.warmup, max(1, min(args.reps, 3)), n_check)
+        ref_mode = {"tol": 1e-6, "value": args.batch * args.steps / m2["wall"],
+                    "ms_per_step": m2["wall"] * 1e3 / args.steps, "mean_arnoldi_last_tick": float(np.mean(m2["n_ax"])),
+                    "parity": m2["parity"]}
+    weak = None
+    if world > 1 and not args.no_weak:
+        mw = measure(shard_inputs(args.batch * world), args.tol, args.steps, args.warmup, max(1, min(args.reps, 3)), 0)
+        weak = {"scaling": "weak", "batch_per_gpu": mw["B"], "global_batch": args.batch * world,
+                "value": args.batch * world * args.steps / mw["wall"], "ms_per_step": mw["wall"] * 1e3 / args.steps}
 
     kernel_name = {1: "tick_lane_kernel", 2: "tick_wg_kernel"}[resolved["variant"]]
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source_committed_profile": traffic_src,
+                "measured_GBps": (traffic / (launch_ms * 1e-3) / 1e9) if traffic else None,
+                "kernel": f"{kernel_name} ({tpl} control step(s) of the batch per launch)", "launch_ms": launch_ms,
+                "ticks_per_launch": args.steps / n_launches, "algorithmic_bytes_per_launch": bytes_per_launch,
+                "rank": 0, "instances_per_launch": B}
+    try:
+        roofline["issue_slot_model"] = json.load(open(ISSUE_MODEL))
+    except OSError:
+        pass
     out = {
         "metric": "C/GMRES control steps/sec, batch=4096 N=50 kmax=10; HBM GB/s vs roofline",
         "value": value, "unit": "control steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic", "reps": args.reps,
+        "rep_ms_per_step": [w * 1e3 / args.steps for w in m["walls"]],
         "config": {"workload": "arm_type_inverted_pendulum controllers, closed loop with on-device Euler plant",
-                   "batch_per_gpu": B, "global_batch": B * world, "N": DV, "kmax": KMAX, "tol": args.tol,
+                   "global_batch": args.batch, "batch_per_gpu": B, "N": DV, "kmax": KMAX, "tol": args.tol,
                    "mode": "fixed-k (tol=0, every instance runs k_max Arnoldi iterations)" if args.tol == 0
-                   else "reference early-exit", "variant": resolved["variant"], "parallelism": f"batch-shard x{world}",
+                   else "reference early-exit", "variant": resolved["variant"],
+                   "parallelism": f"batch-shard x{world} (fixed global batch)",
                    "inputs": "splitmix64(12345) perturbed x0/targets, Newton-initialised U0 (SURVEY.md §8d)"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": f"{kernel_name} ({tpl} control step(s) of the batch per launch)", "launch_ms": launch_ms,
-                     "ticks_per_launch": args.steps / n_launches, "algorithmic_bytes_per_launch": bytes_per_launch},
+        "roofline": roofline,
+        "parity": m["parity"],
     }
     if ref_mode:
         out["reference_mode"] = ref_mode
+    if weak:
+        out["weak_scaling"] = weak
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(B, args.tol, args.warmup, args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(args.batch, args.tol, min(args.warmup, 50) or 5, args.cpu_seconds)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -1,0 +1,180 @@
+"""GPU parity of the BENCHMARKED entry point: cgmres_hip_closed_loop_device on the wg mapping — several control
+ticks fused per launch (CGMRES_HIP_TICKS_PER_LAUNCH), the controller state carried on chip between them and handed
+over through HBM between launches — against the oracle's free-running closed loop with the example's Euler plant
+(<example>/main.cpp:63-73), from the same seeded start.
+
+n in {10, 11, 25, 60} = exactly one full fuse, one launch boundary + a 1-tick tail, two boundaries + a partial
+tail, five boundaries.  Sizes are BASELINE.json's (B = 4096 / 8192); the oracle runs on a spread sample.
+Tolerances: SURVEY.md §8(c) closed loop, first 100 ticks: |du|_inf <= 1e-9 (fp64); fp32 against the fp32 oracle 1e-4.
+"""
+import numpy as np
+import pytest
+
+import cgmres_cpp_amd as cg
+
+pytestmark = pytest.mark.gpu
+
+N_TICKS = (10, 11, 25, 60)
+
+# id -> (model, dv, kmax, tol, dtype, B, variant)
+CASES = {
+    "pendulum_B4096_fixedk": (0, 50, 10, 0.0, "f64", 4096, 2),      # the bench.py headline mode
+    "pendulum_B4096_tolref": (0, 50, 10, 1e-6, "f64", 4096, 2),     # bench.py's reference_mode leg
+    "msd_B4096_fh_hbm": (1, 50, 10, 1e-6, "f64", 4096, 2),          # MAXM = 20 kernel, F(U,x+hf,t+h) kept in HBM
+    "msd_B4096_fh_hbm_fixedk": (1, 50, 10, 0.0, "f64", 4096, 2),
+    "semiactive_B4096": (2, 50, 10, 1e-6, "f64", 4096, 2),          # BASELINE configs[2]
+    "semiactive_B4096_fixedk": (2, 50, 10, 0.0, "f64", 4096, 2),
+    "pendulum_f32_N100_k20_B8192": (0, 100, 20, 1e-6, "f32", 8192, 2),  # configs[4] per-GPU share
+    "pendulum_B200_lane": (0, 50, 10, 1e-6, "f64", 200, 1),         # the lane mapping: one tick per launch
+    "msd_dv20_k5_B33": (1, 20, 5, 1e-6, "f64", 33, 2),              # ragged batch, shipped-size MSD (IPW rows unused)
+}
+
+
+def sample_of(B, n=46):
+    step = max(1, B // n)
+    s = list(range(0, B, step))[:n]
+    for extra in (B - 1, B // 2 + 1, 15, 16):  # last instance, a mid one, both sides of a workgroup edge
+        if 0 <= extra < B and extra not in s:
+            s.append(extra)
+    return sorted(s)
+
+
+class OracleLoop:
+    """Free-running closed loops of the sampled instances on the oracle, with snapshots at the requested ticks."""
+
+    def __init__(self, orc, model, dv, kmax, tol, dtype, x0, u0, p, sample, snaps):
+        self.f32 = dtype == "f32"
+        self.snap = {}
+        npdt = np.float32 if self.f32 else np.float64
+        ctrls, xs = [], []
+        for i in sample:
+            c = orc.Controller(model, dv, kmax, tol, dtype)
+            orc.start_controller(c, x0[i], u0[i], p[i])
+            ctrls.append(c)
+            xs.append(np.array(x0[i], dtype=npdt))
+        u_last = [None] * len(sample)
+        for tick in range(1, max(snaps) + 1):
+            for j, c in enumerate(ctrls):
+                u = c.control(xs[j])
+                f = c.plant(xs[j], u)
+                # plant step in the controller's precision (the device does x + f*dt in T)
+                xs[j] = (xs[j] + f.astype(npdt) * npdt(c.dt)).astype(npdt)
+                u_last[j] = u
+            if tick in snaps:
+                self.snap[tick] = dict(
+                    x=np.array(xs, dtype=np.float64), u=np.array(u_last),
+                    state=[c.get_state() for c in ctrls], solve=[c.last_solve() for c in ctrls])
+
+
+_oracle_cache = {}
+
+
+def oracle_for(orc, name):
+    if name not in _oracle_cache:
+        model, dv, kmax, tol, dtype, B, _ = CASES[name]
+        x0, u0, p = orc.batch_scenario(model, B)
+        sample = sample_of(B)
+        _oracle_cache[name] = (x0, u0, p, sample,
+                               OracleLoop(orc, model, dv, kmax, tol, dtype, x0, u0, p, sample, set(N_TICKS)))
+    return _oracle_cache[name]
+
+
+@pytest.mark.parametrize("n", N_TICKS)
+@pytest.mark.parametrize("name", list(CASES))
+def test_closed_loop_device_vs_oracle(orc, name, n):
+    model, dv, kmax, tol, dtype, B, variant = CASES[name]
+    x0, u0, p, sample, ol = oracle_for(orc, name)
+    f32 = dtype == "f32"
+    npdt = np.float32 if f32 else np.float64
+    c = cg.CgmresBatch(model, batch=B, dv=dv, k_max=kmax, tol=tol, dtype=dtype, variant=variant)
+    assert c.variant == variant
+    c.set_ptau_repeat(p)
+    c.init_u0(u0)
+    c.init_u0_newton(u0, x0, p, 10)
+    xd = c.device_buffer((B, c.dim_x)).upload(x0.astype(npdt))
+    ud = c.device_buffer((B, c.dim_u))
+    c.closed_loop_device(xd, ud, n)
+    c.synchronize()
+    x, u = xd.download().astype(np.float64), ud.download().astype(np.float64)
+    t, U, d = c.get_state()
+    n_ax, reason = c.get_status()
+    xd.free(), ud.free(), c.close()
+    assert np.all(np.isfinite(x)) and np.all(np.isfinite(u)) and np.all(np.isfinite(U)) and np.all(np.isfinite(d))
+    if tol == 0.0:
+        assert np.all(n_ax == kmax) and np.all(reason == cg.EXIT_NATURAL)
+    s = ol.snap[n]
+    u_tol, x_tol, d_rel = (1e-4, 1e-4, 2e-3) if f32 else (1e-9, 1e-9, 1e-7)
+    flips = 0
+    for j, i in enumerate(sample):
+        t_o, U_o, d_o = s["state"][j]
+        assert abs(t - t_o) <= (1e-6 if f32 else 1e-12), (t, t_o)
+        assert np.max(np.abs(u[i] - s["u"][j])) <= u_tol, (name, n, i, u[i], s["u"][j])
+        assert np.max(np.abs(x[i] - s["x"][j])) <= x_tol, (name, n, i, x[i], s["x"][j])
+        assert np.max(np.abs(U[i].astype(np.float64) - U_o)) <= u_tol, (name, n, i)
+        scale = max(1.0, float(np.max(np.abs(d_o))))
+        assert np.max(np.abs(d[i].astype(np.float64) - d_o)) <= d_rel * scale, (name, n, i)
+        k_o, _, reason_o = s["solve"][j]
+        if f32:
+            flips += int(n_ax[i] != k_o)  # fp32: the exit test sits in the rounding noise on many ticks
+        else:
+            assert n_ax[i] == k_o and reason[i] == reason_o, (name, n, i, n_ax[i], k_o, reason[i], reason_o)
+    if f32:
+        assert flips <= len(sample) // 2, flips
+
+
+def test_closed_loop_device_resumes_across_calls(orc):
+    """Two calls (7 + 18 ticks) == one call of 25 ticks, bit for bit: the hand-over of (U, dUdt, x, t) through HBM at
+    a launch boundary does not depend on where the caller cuts the loop."""
+    model, dv, kmax, B = 0, 50, 10, 300
+    x0, u0, p = orc.batch_scenario(model, B)
+
+    def run(parts):
+        c = cg.CgmresBatch(model, batch=B, dv=dv, k_max=kmax)
+        c.set_ptau_repeat(p)
+        c.init_u0(u0)
+        c.init_u0_newton(u0, x0, p, 10)
+        xd = c.device_buffer((B, 4)).upload(x0)
+        ud = c.device_buffer((B, 3))
+        for m in parts:
+            c.closed_loop_device(xd, ud, m)
+        c.synchronize()
+        out = (xd.download(), ud.download(), c.get_state(), c.get_status())
+        xd.free(), ud.free(), c.close()
+        return out
+    a, b = run([25]), run([7, 18])
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert a[2][0] == b[2][0] and np.array_equal(a[2][1], b[2][1]) and np.array_equal(a[2][2], b[2][2])
+    assert np.array_equal(a[3][0], b[3][0])
+
+
+def test_multiple_controller_device_loop_vs_oracle(orc):
+    """BASELINE configs[3] shape on one GPU: MultipleController.closed_loop_device — a Model1 (MSD) batch and a Model2
+    (pendulum) batch, each on its own stream, launches interleaved (multiple_controller/main.cpp:104-118) — for 25
+    ticks, every member against the oracle's free-running loops."""
+    from cgmres_cpp_amd.multi import MultipleController
+    n, dv, km = 25, 50, 10
+    specs = [dict(model="msd", batch=72, dv=dv, k_max=km), dict(model="pendulum", batch=88, dv=dv, k_max=km)]
+    mc = MultipleController(specs)
+    xs, us, want = [], [], []
+    for m, model in zip(mc.members, (1, 0)):
+        x0, u0, p = orc.batch_scenario(model, m.batch)
+        m.set_ptau_repeat(p)
+        m.init_u0(u0)
+        m.init_u0_newton(u0, x0, p, 10)
+        xs.append(m.device_buffer((m.batch, m.dim_x)).upload(x0))
+        us.append(m.device_buffer((m.batch, m.dim_u)))
+        sample = sample_of(m.batch, 12)
+        want.append((sample, OracleLoop(orc, model, dv, km, 1e-6, "f64", x0, u0, p, sample, {n})))
+    mc.closed_loop_device(xs, us, n)
+    mc.synchronize()
+    for m, xd, ud, (sample, ol) in zip(mc.members, xs, us, want):
+        x, u = xd.download(), ud.download()
+        n_ax, _ = m.get_status()
+        s = ol.snap[n]
+        for j, i in enumerate(sample):
+            assert np.max(np.abs(u[i] - s["u"][j])) <= 1e-9, (m.model, i)
+            assert np.max(np.abs(x[i] - s["x"][j])) <= 1e-9, (m.model, i)
+            assert n_ax[i] == s["solve"][j][0]
+        assert abs(m.t - n * m.dt) < 1e-12
+        xd.free(), ud.free()
+    mc.close()
