@@ -178,6 +178,9 @@ def main():
     ap.add_argument("--no-ref-mode", action="store_true", help="skip the secondary tol=1e-6 measurement")
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the secondary weak-scaling measurement")
     ap.add_argument("--check-sample", type=int, default=48, help="instances per rank checked against the oracle")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the real thing); gloo = rehearsal of the N > 1 path on a box with fewer "
+                         "GPUs than ranks (ranks share devices, collectives go through host tensors)")
     args = ap.parse_args()
 
     import torch
@@ -195,11 +198,17 @@ def main():
                  f"--nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: there is no CPU path")
+    if args.backend == "gloo":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where collective buffers live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
         assert dist.get_world_size() == args.gpus
 
     stream = torch.cuda.current_stream().cuda_stream
@@ -208,7 +217,7 @@ def main():
     def shard_inputs(n_global):
         """rank 0 draws the whole job (seeded); the shards go out over RCCL — the only exchange of the job"""
         full = scenarios.batch(MODEL, n_global) if rank == 0 else (None, None, None)
-        parts = [scatter_rows(full[k], n_global, w, world, rank, dev, dist) for k, w in enumerate((DIM_X, DIM_U, DIM_P))]
+        parts = [scatter_rows(full[k], n_global, w, world, rank, cdev, dist) for k, w in enumerate((DIM_X, DIM_U, DIM_P))]
         torch.cuda.synchronize()
         lo, hi = shard_bounds(n_global, world, rank)
         out = [t.cpu().numpy() for t in parts]
@@ -256,7 +265,7 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
             wall = time.perf_counter() - t0
-            tt = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=dev)
+            tt = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=cdev)
             if world > 1:
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             walls.append(tt[0].item()), kernels.append(tt[1].item())
@@ -279,7 +288,7 @@ def main():
         except ParityError as e:
             err = str(e)
         ctrl.close()
-        bad = torch.tensor([0 if (err is None and finite) else 1], dtype=torch.int32, device=dev)
+        bad = torch.tensor([0 if (err is None and finite) else 1], dtype=torch.int32, device=cdev)
         if world > 1:
             dist.all_reduce(bad, op=dist.ReduceOp.MAX)
         if err is not None or not finite:
@@ -342,7 +351,8 @@ def main():
                    "global_batch": args.batch, "batch_per_gpu": B, "N": DV, "kmax": KMAX, "tol": args.tol,
                    "mode": "fixed-k (tol=0, every instance runs k_max Arnoldi iterations)" if args.tol == 0
                    else "reference early-exit", "variant": resolved["variant"],
-                   "parallelism": f"batch-shard x{world} (fixed global batch)",
+                   "parallelism": f"batch-shard x{world} (fixed global batch)" +
+                                  ("" if args.backend == "nccl" else " [gloo rehearsal: ranks share GPUs]"),
                    "inputs": "splitmix64(12345) perturbed x0/targets, Newton-initialised U0 (SURVEY.md §8d)"},
         "roofline": roofline,
         "parity": m["parity"],

@@ -175,19 +175,53 @@ class DeviceBuffer:
         self.ptr = None
 
 
-def _ptr(a):
-    """Device/host address of a numpy array, a DeviceBuffer, a torch tensor or a raw int."""
+def parse_dtype(dtype):
+    """F64 / F32 from 'f64' | 'float64' | np.float64 | torch.float64 | F64 (and the fp32 spellings); anything else is a
+    TypeError — a silent fp64 default would make the kernels read 8-byte elements from a caller's 4-byte buffers."""
+    if isinstance(dtype, (int, np.integer)) and not isinstance(dtype, bool) and int(dtype) in (F64, F32):
+        return int(dtype)
+    name = dtype if isinstance(dtype, str) else None
+    if name is None and dtype is not None:
+        s = str(dtype)
+        if s.startswith("torch."):
+            name = s[6:]
+        else:
+            try:
+                name = np.dtype(dtype).name
+            except TypeError:
+                name = None
+    table = {"f64": F64, "float64": F64, "double": F64, "f32": F32, "float32": F32, "float": F32, "single": F32}
+    if name not in table:
+        raise TypeError(f"dtype must be fp64 or fp32, got {dtype!r}")
+    return table[name]
+
+
+def _ptr(a, dtype=None, numel=None):
+    """Device/host address of a numpy array, a DeviceBuffer, a torch tensor or a raw int.  With dtype/numel the
+    element type and element count of typed containers are checked (raw ints cannot be)."""
     if a is None:
         return None
-    if isinstance(a, DeviceBuffer):
-        return a.ptr
-    if isinstance(a, np.ndarray):
-        return a.ctypes.data
     if isinstance(a, int):
         return a
-    if hasattr(a, "data_ptr"):
-        return a.data_ptr()
-    raise TypeError(type(a))
+    have_dt, have_n = None, None
+    if isinstance(a, DeviceBuffer):
+        ptr, have_dt, have_n = a.ptr, a.dtype, int(np.prod(a.shape))
+    elif isinstance(a, np.ndarray):
+        if not a.flags["C_CONTIGUOUS"]:
+            raise ValueError("array must be C-contiguous")
+        ptr, have_dt, have_n = a.ctypes.data, a.dtype, a.size
+    elif hasattr(a, "data_ptr"):
+        if hasattr(a, "is_contiguous") and not a.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+        ptr, have_n = a.data_ptr(), int(a.numel())
+        have_dt = np.dtype(str(a.dtype)[6:]) if str(a.dtype).startswith("torch.") else None
+    else:
+        raise TypeError(type(a))
+    if dtype is not None and have_dt is not None and np.dtype(have_dt) != np.dtype(dtype):
+        raise TypeError(f"buffer holds {np.dtype(have_dt).name}, the controller computes in {np.dtype(dtype).name}")
+    if numel is not None and have_n is not None and have_n != numel:
+        raise ValueError(f"buffer holds {have_n} elements, expected {numel}")
+    return ptr
 
 
 class CgmresBatch:
@@ -205,7 +239,7 @@ class CgmresBatch:
         cfg = Config()
         _check(lib.cgmres_hip_default_config(self.model, C.byref(cfg)))
         cfg.batch = int(batch)
-        cfg.dtype = F32 if dtype in ("f32", np.float32, F32) and dtype != F64 else F64
+        cfg.dtype = parse_dtype(dtype)
         if dv is not None:
             cfg.dv = int(dv)
         if k_max is not None:
@@ -297,10 +331,12 @@ class CgmresBatch:
         return u
 
     def control_device(self, u_dev, x_dev):
-        _check(load().cgmres_hip_control_device(self._h, _ptr(u_dev), _ptr(x_dev)))
+        _check(load().cgmres_hip_control_device(self._h, _ptr(u_dev, self.np_dtype, self.batch * self.dim_u),
+                                                _ptr(x_dev, self.np_dtype, self.batch * self.dim_x)))
 
     def closed_loop_device(self, x_dev, u_dev, n_ticks):
-        _check(load().cgmres_hip_closed_loop_device(self._h, _ptr(x_dev), _ptr(u_dev), int(n_ticks)))
+        _check(load().cgmres_hip_closed_loop_device(self._h, _ptr(x_dev, self.np_dtype, self.batch * self.dim_x),
+                                                    _ptr(u_dev, self.np_dtype, self.batch * self.dim_u), int(n_ticks)))
 
     def synchronize(self):
         _check(load().cgmres_hip_synchronize(self._h))

@@ -8,6 +8,7 @@
 // There is no CPU implementation of the path in this library.
 #include <dlfcn.h>
 
+#include <deque>
 #include <mutex>
 
 #include "ctx_common.hip.h"
@@ -27,8 +28,8 @@ struct Plugin {
   int (*probe)(const double*, const double*, const double*, const double*, double*, void*);
   const char* (*last_error)(void);
 };
-std::vector<Plugin>& plugins() {
-  static std::vector<Plugin> v;
+std::deque<Plugin>& plugins() {  // deque: find_plugin hands out pointers that must survive later push_backs
+  static std::deque<Plugin> v;
   return v;
 }
 std::mutex& plugins_mutex() {

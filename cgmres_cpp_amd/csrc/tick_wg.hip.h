@@ -57,6 +57,7 @@ struct WgParams {
   T *U, *dUdt, *Fh, *V, *xdxh, *ptau;  // [B][Lg], [B][Lg], [B][Lg], [B][kmax+1][Lv], [B][NX], [B][NP*(dv+1)]
   T* kry;                              // [B][KS]: H (k1*k1 col-major) | rho (k1) | g (3*kmax)
   T* scr;                              // [workgroups][2][dv*NSTG*IPW]: parked stage tables of the preamble sweeps
+  T* park;                             // [workgroups*IPW][Lv]: the solution vector during the Arnoldi loop (MAXM > 10 only)
   int *n_ax, *reason;
   const T* x_in;  // [B][NX]
   T* u_out;       // [B][NU]
@@ -749,6 +750,15 @@ struct WgCtx {
     constexpr int NBUF = MAXM <= 10 ? CGM_AB_NBUF : 2, KRING = 12;
     const bool preload = kmax <= KRING;  // workgroup-uniform; longer bases use the plain streaming loop
     bool active = valid;
+    // Long vectors: x is not touched again before the final update (gmres.hpp:110-111), and 2*MAXM more live registers
+    // push the Gram-Schmidt rounds into AGPR copies and scratch (profiles/r02_isa_summary.md).  Park it in HBM
+    // (own row, same thread writes and reads it back: program order) and fetch it back behind the back substitution.
+    T* const park_row = P.park + size_t(blockIdx.x * IPW + inst) * P.Lv;
+#ifndef CGM_AB_PARK
+#define CGM_AB_PARK 1
+#endif
+    constexpr bool PARK = MAXM > 10 && CGM_AB_PARK;
+    if constexpr (PARK) store_vec(park_row, xv);
     // r0 = b - A x0 ; rho = ||r0||      gmres.hpp:33-37
     {
       T ss = 0;
@@ -948,6 +958,7 @@ struct WgCtx {
         S.ksolve[inst] = ks;
       }
     }
+    if constexpr (PARK) load_vec(xv, park_row);
     __syncthreads();
     CGM_STAMP(*this, 11);
     if (valid && reason <= 1) {
@@ -1033,6 +1044,14 @@ __global__ __launch_bounds__(IPW * 16) __attribute__((amdgpu_waves_per_eu(1, 1))
       C.reg_to_row(P.dUdt, P.Lg, du);
       if (C.valid && C.r < M::NU) P.u_out[size_t(C.b) * M::NU + C.r] = un[0];  // element e = r (m = 0), r < NU <= 16
       C.store_status();
+      // x_dxh and F_dxh_h of this tick stay with the controller like the reference's members (cgmres.hpp:198-201):
+      // a white-box Ax_func after control() evaluates with them (with fh_hbm the preamble has stored the row already)
+      if (!C.fh_hbm()) {
+        T fh[MAXM];
+        C.lds_to_reg(fh, C.S.Fh);
+        C.reg_to_row(P.Fh, P.Lg, fh);
+      }
+      if (C.valid && C.r < M::NX) P.xdxh[size_t(C.b) * M::NX + C.r] = C.S.xh[C.r * IPW + C.inst];
     }
     C.reg_to_lds(C.S.U, un);  // the plant step and the next tick read U from LDS
     if (P.x_next) {  // plant step of the example main loop (<example>/main.cpp:71-73)

@@ -4,6 +4,7 @@ import ctypes
 import os
 import re
 
+import numpy as np
 import pytest
 
 import cgmres_cpp_amd as cg
@@ -75,3 +76,27 @@ def test_scenarios_match_checker_recipe(orc):
     for m in (0, 1, 2):
         for a, b in zip(orc.batch_scenario(m, 33), scenarios.batch(m, 33)):
             assert np.array_equal(a, b)
+
+
+def test_dtype_spellings_and_buffer_checks():
+    """Every fp32/fp64 spelling resolves; anything else raises (no silent fp64 default); typed buffers handed to the
+    device entry points are checked for element type and count before their address crosses the ABI."""
+    import torch
+    for d in ("f64", "float64", np.float64, np.dtype("float64"), torch.float64, cg.F64):
+        assert cg.parse_dtype(d) == cg.F64
+    for d in ("f32", "float32", np.float32, np.dtype("float32"), torch.float32, cg.F32):
+        assert cg.parse_dtype(d) == cg.F32
+    for d in ("f16", np.int32, torch.bfloat16, 2, None, True):
+        with pytest.raises(TypeError):
+            cg.parse_dtype(d)
+    t = torch.zeros(4, 3, dtype=torch.float32)
+    assert cg._ptr(t, np.float32, 12) == t.data_ptr()
+    with pytest.raises(TypeError):
+        cg._ptr(t, np.float64, 12)
+    with pytest.raises(ValueError):
+        cg._ptr(t, np.float32, 16)
+    with pytest.raises(ValueError):
+        cg._ptr(t.t(), np.float32, 12)
+    a = np.zeros((4, 3))
+    assert cg._ptr(a, np.float64, 12) == a.ctypes.data
+    assert cg._ptr(12345) == 12345 and cg._ptr(None) is None

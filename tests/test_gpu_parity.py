@@ -394,6 +394,34 @@ def test_status_exit_paths(orc, variant):
     assert np.array_equal(U1, U0)
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("model,dv,kmax", [(0, 50, 10), (1, 50, 10), (2, 50, 10)])
+def test_ax_func_after_control(orc, model, dv, kmax, variant):
+    """The facade's Ax_func (cgmres.hpp:164-175) after control(): x_dxh and F_dxh_h are the ones control() left
+    behind (cgmres.hpp:85,88), U and t the advanced ones — exactly the members the reference would read.  Both
+    mappings must agree with the oracle (MSD at dv = 50 runs the fh_hbm plan of the wg mapping)."""
+    B = 19
+    x0, u0, p = orc.batch_scenario(model, B)
+    c = cg.CgmresBatch(model, batch=B, dv=dv, k_max=kmax, variant=variant)
+    c.set_ptau_repeat(p)
+    c.init_u0(u0)
+    c.init_u0_newton(u0, x0, p, 10)
+    refs = _oracle_batch(orc, model, dv, kmax, 1e-6, x0, u0, p)
+    x = x0.copy()
+    rng = np.random.default_rng(3)
+    for tick in range(3):
+        u = c.control(x)
+        v = rng.standard_normal((B, c.len))
+        ax = c.Ax_func(v)
+        for i, r in enumerate(refs):
+            ur = r.control(x[i])
+            ar = r.Ax(v[i])
+            assert np.max(np.abs(u[i] - ur)) <= U_TOL * (1 + tick)
+            assert np.max(np.abs(ax[i] - ar)) <= 1e-7 * max(1.0, float(np.max(np.abs(ar)))), (tick, i)
+            x[i] = x[i] + r.plant(x[i], ur) * r.dt
+    c.close()
+
+
 def test_device_sincos_accuracy():
     """The fp64 sin/cos of the horizon sweeps against the host libm: <= 2 ulp of the result on the ranges the
     models visit (angles around pi, arguments up to the 1e5 cut-over to the library path) and beyond it."""

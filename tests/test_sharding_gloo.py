@@ -82,3 +82,58 @@ def test_two_rank_gloo_job_equals_single_process(tmp_path, orc):
         u, _, _, _ = orc.closed_loop(c, x0[i], 4)
         want.append(u[-1])
     assert np.array_equal(got, np.array(want))
+
+
+MIXED_WORKER = textwrap.dedent('''
+    import os, sys
+    sys.path.insert(0, os.environ["REPO_ROOT"])
+    import numpy as np, torch, torch.distributed as dist
+    from cgmres_cpp_amd import scenarios
+    from cgmres_cpp_amd.sharding import gather_rows, shard_bounds
+    from oracle import orc
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    TICKS, DV, KM = 3, 8, 3
+    out = {}
+    # BASELINE configs[3] shape: EACH model's sub-batch is split over all ranks (tools/bench_configs.py --config 4)
+    for name, model, n in (("msd", orc.MSD, 5), ("pendulum", orc.PENDULUM, 7)):
+        x0, u0, p = scenarios.batch(name, n)       # seeded: every rank draws the job and keeps its slice
+        lo, hi = shard_bounds(n, world, rank)
+        us = []
+        for i in range(lo, hi):
+            c = orc.Controller(model, DV, KM)
+            orc.start_controller(c, x0[i], u0[i], p[i])
+            u, _, _, _ = orc.closed_loop(c, x0[i], TICKS)
+            us.append(u[-1])
+        got = gather_rows(torch.tensor(np.array(us)), n, world, rank, dist)
+        if rank == 0:
+            out[name] = got
+    if rank == 0:
+        np.savez(os.environ["OUT_NPY"], **out)
+    dist.barrier()
+    dist.destroy_process_group()
+''')
+
+
+def test_two_rank_mixed_batch_equals_single_process(tmp_path, orc):
+    """multiple_controller's heterogeneous batch over 2 ranks: each model's sub-batch sharded over both ranks (uneven
+    splits 3+2 and 4+3), gathered per model == what one process computes."""
+    script = tmp_path / "worker_mixed.py"
+    script.write_text(MIXED_WORKER)
+    out = tmp_path / "u.npz"
+    env = dict(os.environ, REPO_ROOT=ROOT, OUT_NPY=str(out), MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(script)],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    got = np.load(out)
+    from cgmres_cpp_amd import scenarios
+    for name, model, n in (("msd", orc.MSD, 5), ("pendulum", orc.PENDULUM, 7)):
+        x0, u0, p = scenarios.batch(name, n)
+        want = []
+        for i in range(n):
+            c = orc.Controller(model, 8, 3)
+            orc.start_controller(c, x0[i], u0[i], p[i])
+            u, _, _, _ = orc.closed_loop(c, x0[i], 3)
+            want.append(u[-1])
+        assert np.array_equal(got[name], np.array(want)), name

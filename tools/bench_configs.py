@@ -1,14 +1,33 @@
 #!/usr/bin/env python3
-"""Secondary measurements (not bench lines): the other BASELINE.json configurations on one GPU, closed loop on the
-device with the example plants, fixed-k mode (tol = 0) and reference mode (tol = 1e-6).
-    python tools/bench_configs.py > gpurun_out/configs.json"""
-import json, os, sys, time
+"""Secondary measurements (not bench lines): the other BASELINE.json configurations, closed loop on the device with
+the example plants, fixed-k mode (tol = 0) and reference mode (tol = 1e-6).
+
+    python tools/bench_configs.py [--config all|1|2|3|4|5|headline] [--steps K] [--warmup W] > gpurun_out/configs.jsonl
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/bench_configs.py --config 4
+
+Config 4 (multiple_controller: 4096 Model1 = MSD + 4096 Model2 = pendulum controllers, both N = 50) under
+torch.distributed: EACH model's sub-batch is split over all ranks (cgmres_cpp_amd.sharding.shard_bounds — an MSD tick
+moves twice the bytes of a pendulum tick, so model-per-GPU would imbalance), every rank steps its two
+shards on two HIP streams (cgmres_cpp_amd.multi.MultipleController), no collective inside the timed region; the time is
+the max over ranks between barriers.  Config 5 (65536 pendulum controllers, N = 100, k = 20, fp32) is likewise split
+over the ranks (8192 per GPU at 8)."""
+import argparse
+import json
+import os
+import sys
+import time
+
 import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import torch
-import cgmres_cpp_amd as cg
-from cgmres_cpp_amd import scenarios
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import cgmres_cpp_amd as cg  # noqa: E402
+from cgmres_cpp_amd import scenarios  # noqa: E402
+from cgmres_cpp_amd.multi import MultipleController  # noqa: E402
+from cgmres_cpp_amd.sharding import shard_bounds  # noqa: E402
 
 NAMES = {0: "pendulum", 1: "msd", 2: "semiactive"}
 DIMS = {0: (4, 3, 2), 1: (4, 6, 2), 2: (2, 3, 0)}
@@ -20,73 +39,113 @@ def alg_bytes(model, dv, k, scalar):
     return scalar * (L * (8 + 6 * k + k * (k - 1) // 2) + (3 + k) * (npar * (dv + 1) + nx) + nu)
 
 
-def run(model, B, dv, kmax, dtype, tol, steps=100, warmup=50):
-    x0, u0, p = scenarios.batch(NAMES[model], B)
-    npdt = np.float64 if dtype == "f64" else np.float32
-    c = cg.CgmresBatch(model, batch=B, dv=dv, k_max=kmax, tol=tol, dtype=dtype)
-    if DIMS[model][2]:
-        c.set_ptau_repeat(p)
-    c.init_u0(u0)
-    c.init_u0_newton(u0, x0, p, 10)
-    dev = torch.device("cuda", 0)
-    tdt = torch.float64 if dtype == "f64" else torch.float32
-    x = torch.from_numpy(x0.astype(npdt)).to(dev)
-    u = torch.zeros(B, DIMS[model][1], dtype=tdt, device=dev)
-    c.closed_loop_device(x, u, warmup)
-    torch.cuda.synchronize()
-    c.timer_start()
-    c.closed_loop_device(x, u, steps)
-    ms = c.timer_stop() / steps
-    torch.cuda.synchronize()
-    n_ax, _ = c.get_status()
-    ok = bool(torch.isfinite(u).all().item())
-    var = c.variant
-    c.close()
-    k_eff = [int(k) for k in n_ax]
-    by = float(sum(alg_bytes(model, dv, k, 8 if dtype == "f64" else 4) for k in k_eff)) if tol > 0 else \
-        float(B * alg_bytes(model, dv, kmax, 8 if dtype == "f64" else 4))
-    return {"model": NAMES[model], "batch": B, "dv": dv, "kmax": kmax, "dtype": dtype, "tol": tol, "variant": var,
-            "ms_per_tick": ms, "steps_per_s": B / ms * 1e3, "mean_arnoldi_last_tick": float(np.mean(n_ax)),
-            "algorithmic_GBps": by / ms / 1e6, "frac_of_8TBps": by / ms / 1e6 / 8000.0, "finite": ok}
+def job_bytes(model, dv, kmax, dtype, tol, n_ax, B):
+    s = 8 if dtype == "f64" else 4
+    return float(sum(alg_bytes(model, dv, int(k), s) for k in n_ax)) if tol > 0 else float(B * alg_bytes(model, dv, kmax, s))
 
 
-out = []
-for args in [(2, 4096, 50, 10, "f64"), (1, 4096, 50, 10, "f64"), (0, 4096, 50, 10, "f64"),
-             (0, 8192, 100, 20, "f32"), (0, 256, 50, 10, "f64"), (1, 1, 20, 5, "f64")]:
-    for tol in (0.0, 1e-6):
-        out.append(run(*args, tol))
-        print(json.dumps(out[-1]), flush=True)
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="all")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--tols", default="0,1e-6")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal with ranks sharing GPUs")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.backend == "gloo":
+        local = local % torch.cuda.device_count()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(label, members, tol, dtype="f64"):
+        """members: list of (model, global batch, dv, kmax); every member's batch is sharded over the ranks and the
+        members of one rank run on their own streams."""
+        specs, shards = [], []
+        for model, Bg, dv, kmax in members:
+            lo, hi = shard_bounds(Bg, world, rank)
+            specs.append(dict(model=model, batch=hi - lo, dv=dv, k_max=kmax, tol=tol, dtype=dtype, device=local))
+            shards.append((lo, hi))
+        streams = [torch.cuda.Stream(device=dev) for _ in members]
+        mc = MultipleController(specs, device=local, streams=[s.cuda_stream for s in streams])
+        tdt = torch.float64 if dtype == "f64" else torch.float32
+        xs, us = [], []
+        for m, (model, Bg, dv, kmax), (lo, hi) in zip(mc.members, members, shards):
+            x0, u0, p = scenarios.batch(NAMES[model], Bg)  # seeded: every rank draws the job and keeps its slice
+            x0, u0, p = x0[lo:hi], u0[lo:hi], p[lo:hi]
+            if DIMS[model][2]:
+                m.set_ptau_repeat(p)
+            m.init_u0(u0)
+            m.init_u0_newton(u0, x0, p, 10)
+            xs.append(torch.from_numpy(np.ascontiguousarray(x0)).to(dev, tdt))
+            us.append(torch.zeros(hi - lo, DIMS[model][1], dtype=tdt, device=dev))
+        torch.cuda.synchronize()  # the torch allocations/copies above ran on torch's stream, the launches do not
+        mc.closed_loop_device(xs, us, args.warmup)
+        mc.synchronize()
+        sync_all()
+        t0 = time.perf_counter()
+        mc.closed_loop_device(xs, us, args.steps)
+        mc.synchronize()
+        sync_all()
+        dt = time.perf_counter() - t0
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        by = torch.zeros(1, dtype=torch.float64, device=cdev)
+        ok = torch.tensor([1 if all(bool(torch.isfinite(u).all().item()) for u in us) else 0], device=cdev)
+        kmean = []
+        for m, (model, Bg, dv, kmax) in zip(mc.members, members):
+            n_ax, _ = m.get_status()
+            by += job_bytes(model, dv, kmax, dtype, tol, n_ax, m.batch)
+            kmean.append(float(np.mean(n_ax)))
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dist.all_reduce(by, op=dist.ReduceOp.SUM)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        variants = [m.variant for m in mc.members]
+        mc.close()
+        total = sum(b for _, b, _, _ in members)
+        ms = tt.item() / args.steps * 1e3
+        out = {"config": label, "members": [f"{NAMES[m]} B={b} dv={dv} k={k}" for m, b, dv, k in members], "dtype": dtype,
+               "tol": tol, "n_gpus": world, "variants": variants, "ms_per_tick": ms,
+               "steps_per_s": total * args.steps / tt.item(), "mean_arnoldi_last_tick_rank0": kmean,
+               "algorithmic_GBps": by.item() / (ms * 1e-3) / 1e9,
+               "frac_of_8TBps_per_gpu": by.item() / (ms * 1e-3) / 1e9 / 8000.0 / world, "finite": bool(ok.item())}
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+
+    table = {
+        "3": ("cfg3 semiactive", [(2, 4096, 50, 10)], "f64"),
+        "4msd": ("cfg4 MSD half alone", [(1, 4096, 50, 10)], "f64"),
+        "headline": ("headline pendulum", [(0, 4096, 50, 10)], "f64"),
+        "4": ("cfg4 multiple_controller: MSD + pendulum on two streams", [(1, 4096, 50, 10), (0, 4096, 50, 10)], "f64"),
+        "5": (f"cfg5 pendulum N=100 k=20 fp32 ({8192 * world} controllers = 8192 per GPU)",
+              [(0, 8192 * world, 100, 20)], "f32"),
+        "2": ("cfg2 pendulum B=256", [(0, 256, 50, 10)], "f64"),
+        "1": ("cfg1 one MSD controller N=20 k=5", [(1, 1, 20, 5)], "f64"),
+    }
+    keys = list(table) if args.config == "all" else args.config.split(",")
+    for k in keys:
+        label, members, dtype = table[k]
+        for tol in [float(t) for t in args.tols.split(",")]:
+            run(label, members, tol, dtype)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
-def run_mixed(B_each=4096, dv=50, kmax=10, tol=0.0, steps=100, warmup=50):
-    """BASELINE configs[4] on ONE GPU: Model1 (MSD) and Model2 (pendulum) batches stepped in the same loop on two
-    streams (multiple_controller/main.cpp:104-110), host wall clock around both."""
-    from cgmres_cpp_amd.multi import MultipleController
-    dev = torch.device("cuda", 0)
-    mc = MultipleController([dict(model=1, batch=B_each, dv=dv, k_max=kmax, tol=tol),
-                             dict(model=0, batch=B_each, dv=dv, k_max=kmax, tol=tol)])
-    xs, us = [], []
-    for m, mid in zip(mc.members, (1, 0)):
-        x0, u0, p = scenarios.batch(NAMES[mid], B_each)
-        if DIMS[mid][2]:
-            m.set_ptau_repeat(p)
-        m.init_u0(u0)
-        m.init_u0_newton(u0, x0, p, 10)
-        xs.append(torch.from_numpy(x0).to(dev))
-        us.append(torch.zeros(B_each, DIMS[mid][1], dtype=torch.float64, device=dev))
-    mc.closed_loop_device(xs, us, warmup)
-    mc.synchronize()
-    t0 = time.perf_counter()
-    mc.closed_loop_device(xs, us, steps)
-    mc.synchronize()
-    dt = time.perf_counter() - t0
-    ok = all(bool(torch.isfinite(u).all().item()) for u in us)
-    by = B_each * (alg_bytes(1, dv, kmax, 8) + alg_bytes(0, dv, kmax, 8))
-    mc.close()
-    return {"model": "msd+pendulum (two streams)", "batch": 2 * B_each, "dv": dv, "kmax": kmax, "dtype": "f64",
-            "tol": tol, "variant": 2, "ms_per_tick": dt / steps * 1e3, "steps_per_s": 2 * B_each * steps / dt,
-            "mean_arnoldi_last_tick": float(kmax), "algorithmic_GBps": by / (dt / steps) / 1e9,
-            "frac_of_8TBps": by / (dt / steps) / 1e9 / 8000.0, "finite": ok}
-
-
-print(json.dumps(run_mixed()), flush=True)
+if __name__ == "__main__":
+    main()
