@@ -29,7 +29,8 @@ SYMBOLS = [
     "cgmres_hip_last_error",
     "cgmres_hip_device_count", "cgmres_hip_create", "cgmres_hip_destroy", "cgmres_hip_get_config",
     "cgmres_hip_set_ptau", "cgmres_hip_set_ptau_repeat", "cgmres_hip_init_u0", "cgmres_hip_init_u0_newton",
-    "cgmres_hip_control", "cgmres_hip_control_device", "cgmres_hip_closed_loop_device", "cgmres_hip_synchronize",
+    "cgmres_hip_control", "cgmres_hip_control_device", "cgmres_hip_closed_loop_device",
+    "cgmres_hip_closed_loop_device_ptau", "cgmres_hip_synchronize",
     "cgmres_hip_get_time", "cgmres_hip_get_state", "cgmres_hip_set_state", "cgmres_hip_get_status",
     "cgmres_hip_get_krylov", "cgmres_hip_F_func", "cgmres_hip_prepare", "cgmres_hip_Ax_func", "cgmres_hip_gmres",
     "cgmres_hip_timer_start", "cgmres_hip_timer_stop", "cgmres_hip_malloc", "cgmres_hip_free",
@@ -84,6 +85,7 @@ def load():
     lib.cgmres_hip_control.argtypes = [vp, vp, vp]
     lib.cgmres_hip_control_device.argtypes = [vp, vp, vp]
     lib.cgmres_hip_closed_loop_device.argtypes = [vp, vp, vp, i32]
+    lib.cgmres_hip_closed_loop_device_ptau.argtypes = [vp, vp, vp, i32, vp, C.c_int]
     lib.cgmres_hip_synchronize.argtypes = [vp]
     lib.cgmres_hip_get_time.argtypes = [vp, C.POINTER(C.c_double)]
     lib.cgmres_hip_get_state.argtypes = [vp, C.POINTER(C.c_double), vp, vp]
@@ -334,9 +336,17 @@ class CgmresBatch:
         _check(load().cgmres_hip_control_device(self._h, _ptr(u_dev, self.np_dtype, self.batch * self.dim_u),
                                                 _ptr(x_dev, self.np_dtype, self.batch * self.dim_x)))
 
-    def closed_loop_device(self, x_dev, u_dev, n_ticks):
-        _check(load().cgmres_hip_closed_loop_device(self._h, _ptr(x_dev, self.np_dtype, self.batch * self.dim_x),
-                                                    _ptr(u_dev, self.np_dtype, self.batch * self.dim_u), int(n_ticks)))
+    def closed_loop_device(self, x_dev, u_dev, n_ticks, ptau_seq_dev=None, per_instance=True):
+        """n_ticks of the example main loop on the device.  ptau_seq_dev: optional device array of per-tick parameter
+        horizons, [n_ticks, batch, dim_p*(dv+1)] (per_instance) or [n_ticks, dim_p*(dv+1)] — `set_ptau` before every tick."""
+        xp = _ptr(x_dev, self.np_dtype, self.batch * self.dim_x)
+        up = _ptr(u_dev, self.np_dtype, self.batch * self.dim_u)
+        if ptau_seq_dev is None or self.dim_p == 0:
+            _check(load().cgmres_hip_closed_loop_device(self._h, xp, up, int(n_ticks)))
+        else:
+            n = int(n_ticks) * (self.batch if per_instance else 1) * self.dim_p * (self.dv + 1)
+            _check(load().cgmres_hip_closed_loop_device_ptau(self._h, xp, up, int(n_ticks),
+                                                             _ptr(ptau_seq_dev, self.np_dtype, n), 1 if per_instance else 0))
 
     def synchronize(self):
         _check(load().cgmres_hip_synchronize(self._h))

@@ -294,6 +294,13 @@ int cgmres_hip_closed_loop_device(cgmres_hip_handle h, void* x, void* u, int32_t
   if (n_ticks < 0) return fail(CGMRES_HIP_EINVAL, "n_ticks < 0");
   return h->closed_loop(x, u, n_ticks);
 }
+int cgmres_hip_closed_loop_device_ptau(cgmres_hip_handle h, void* x, void* u, int32_t n_ticks, const void* ptau_seq,
+                                       int per_instance) {
+  NEED(h);
+  if (n_ticks < 0) return fail(CGMRES_HIP_EINVAL, "n_ticks < 0");
+  if (h->np && !ptau_seq) return fail(CGMRES_HIP_EINVAL, "closed_loop_device_ptau: null ptau sequence");
+  return h->closed_loop(x, u, n_ticks, h->np ? ptau_seq : nullptr, per_instance);
+}
 int cgmres_hip_synchronize(cgmres_hip_handle h) {
   NEED(h);
   HIP_TRY(hipSetDevice(h->cfg.device));

@@ -101,7 +101,7 @@ struct cgmres_hip_ctx {
   virtual int init_u0_newton(void*, const void*, const void*, int) = 0;
   virtual int control_host(void*, const void*) = 0;
   virtual int control_device(void*, const void*, void* x_next) = 0;
-  virtual int closed_loop(void*, void*, int) = 0;
+  virtual int closed_loop(void*, void*, int, const void* ptau_seq = nullptr, int per_instance = 0) = 0;
   virtual double time() const = 0;
   virtual int get_state(double*, void*, void*) = 0;
   virtual int set_state(double, const void*, const void*) = 0;

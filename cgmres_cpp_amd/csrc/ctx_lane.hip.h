@@ -125,11 +125,20 @@ struct CtxLane final : cgmres_hip_ctx {
     HIP_TRY(hipStreamSynchronize(stream));
     return 0;
   }
-  int closed_loop(void* x, void* u, int n_ticks) override {
+  int closed_loop(void* x, void* u, int n_ticks, const void* ptau_seq, int per_instance) override {
     HIP_TRY(hipSetDevice(cfg.device));
     if (!u || !x) return fail(CGMRES_HIP_EINVAL, "closed_loop: null pointer");
-    for (int i = 0; i < n_ticks; ++i)
+    const int all = np * (cfg.dv + 1);
+    const size_t per_tick = size_t(per_instance ? cfg.batch : 1) * all;
+    for (int i = 0; i < n_ticks; ++i) {
+      if (ptau_seq && all) {  // set_ptau before this tick (cgmres.hpp:36-39), device to device
+        dim3 grid((cfg.batch + 255) / 256, all);
+        to_element_major<T><<<grid, 256, 0, stream>>>(P.ptau, static_cast<const T*>(ptau_seq) + i * per_tick, cfg.batch,
+                                                       ldb, all, !per_instance);
+        HIP_TRY(hipGetLastError());
+      }
       if (int rc = launch_tick(static_cast<T*>(u), static_cast<const T*>(x), static_cast<T*>(x))) return rc;
+    }
     return 0;
   }
 

@@ -195,14 +195,26 @@ struct CtxWg final : cgmres_hip_ctx {
     HIP_TRY(hipStreamSynchronize(stream));
     return 0;
   }
-  int closed_loop(void* x, void* u, int n_ticks) override {
+  int closed_loop(void* x, void* u, int n_ticks, const void* ptau_seq, int per_instance) override {
     HIP_TRY(hipSetDevice(cfg.device));
     if (!u || !x) return fail(CGMRES_HIP_EINVAL, "closed_loop: null pointer");
-    for (int i = 0; i < n_ticks; i += CGM_FUSE_MAX) {
+    const int all = np * (cfg.dv + 1);
+    const T* seq = all ? static_cast<const T*>(ptau_seq) : nullptr;
+    const size_t per_tick = size_t(per_instance ? cfg.batch : 1) * all;
+    P.pseq_tick = per_tick, P.pseq_inst = per_instance ? all : 0;
+    int rc = 0;
+    for (int i = 0; i < n_ticks && !rc; i += CGM_FUSE_MAX) {
       const int n = n_ticks - i < CGM_FUSE_MAX ? n_ticks - i : CGM_FUSE_MAX;
-      if (int rc = launch_ticks(static_cast<T*>(u), static_cast<const T*>(x), static_cast<T*>(x), n)) return rc;
+      P.ptau_seq = seq ? seq + size_t(i) * per_tick : nullptr;  // the kernel reloads ptau at the top of every tick
+      rc = launch_ticks(static_cast<T*>(u), static_cast<const T*>(x), static_cast<T*>(x), n);
     }
-    return 0;
+    P.ptau_seq = nullptr;
+    if (!rc && seq && n_ticks > 0) {  // the handle keeps the last tick's ptau, as set_ptau would (cgmres.hpp:36-39)
+      replicate_rows_im<T><<<dim3(4, cfg.batch), 256, 0, stream>>>(P.ptau, all, seq + size_t(n_ticks - 1) * per_tick,
+                                                                    cfg.batch, all, 1, !per_instance);
+      HIP_TRY(hipGetLastError());
+    }
+    return rc;
   }
 
   double time() const override { return double(t); }

@@ -53,6 +53,11 @@ struct WgParams {
   // horizon steps of tick k (cgmres.hpp:88,91), computed by the host exactly as for single launches
   int n_ticks;
   T dtau_tab[2 * 10];
+  // time-varying reference (cgmres_hip_closed_loop_device_ptau): ptau of tick k of this launch =
+  // ptau_seq[k*pseq_tick + b*pseq_inst + ...]; null = the handle's ptau for every tick
+  const T* ptau_seq;
+  size_t pseq_tick;
+  int pseq_inst;
   // instance-major HBM state
   T *U, *dUdt, *Fh, *V, *xdxh, *ptau;  // [B][Lg], [B][Lg], [B][Lg], [B][kmax+1][Lv], [B][NX], [B][NP*(dv+1)]
   T* kry;                              // [B][KS]: H (k1*k1 col-major) | rho (k1) | g (3*kmax)
@@ -267,6 +272,14 @@ struct WgCtx {
       S.nax[inst] = 0;
       S.ksolve[inst] = 0;
     }
+  }
+
+  // set_ptau before a tick of the fused loop (cgmres.hpp:36-39): this row's parameter horizon -> LDS
+  __device__ __forceinline__ void load_ptau_tick(const T* seq_tick) {
+    if (!valid) return;
+    const int np_all = M::NP * (P.dv + 1);
+    const T* src = seq_tick + size_t(b) * P.pseq_inst;
+    for (int q = r; q < np_all; q += 16) S.p[inst * P.Pp + q] = src[q];
   }
 
   // ---- horizon sweep (cgmres.hpp:113-162; with PERT also :168-169, with MODE the post-processing) ------------
@@ -1026,6 +1039,7 @@ __global__ __launch_bounds__(IPW * 16) __attribute__((amdgpu_waves_per_eu(1, 1))
     C.dtau_h = P.dtau_tab[2 * tk], C.dtau_0 = P.dtau_tab[2 * tk + 1];
     // H region zeroed so the exported Hessenberg has no stale entries
     for (int q = C.r; q < P.Hp; q += 16) C.S.H[C.inst * P.Hp + q] = T(0);
+    if (M::NP > 0 && P.ptau_seq) C.load_ptau_tick(P.ptau_seq + size_t(tk) * P.pseq_tick);
     __syncthreads();
     CGM_STAMP(C, 0);
     C.publish_direction(du);  // direction of the first mat-vec: x0 = dUdt (warm start, cgmres.hpp:99)

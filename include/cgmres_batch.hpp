@@ -52,6 +52,12 @@ class CgmresBatch {
   void closed_loop_device(double* x_dev, double* u_dev, int32_t n_ticks) {
     cgmres_detail::check(cgmres_hip_closed_loop_device(handle_, x_dev, u_dev, n_ticks), "closed_loop_device");
   }
+  // the same loop with set_ptau (cgmres.hpp:36-39) before every tick: ptau_seq_dev [n_ticks][batch][dim_p*(dv+1)]
+  // (per_instance) or [n_ticks][dim_p*(dv+1)] (broadcast), device pointer
+  void closed_loop_device(double* x_dev, double* u_dev, int32_t n_ticks, const double* ptau_seq_dev, bool per_instance) {
+    cgmres_detail::check(cgmres_hip_closed_loop_device_ptau(handle_, x_dev, u_dev, n_ticks, ptau_seq_dev, per_instance ? 1 : 0),
+                         "closed_loop_device_ptau");
+  }
   void synchronize() { cgmres_detail::check(cgmres_hip_synchronize(handle_), "synchronize"); }
 
   // Arnoldi mat-vecs executed and exit reason (CGMRES_HIP_EXIT_*) per instance for the last tick

@@ -130,6 +130,14 @@ int cgmres_hip_control_device(cgmres_hip_handle h, void* u_dev, const void* x_de
  * simulator's forward-Euler plant step x += dxdt(x,u)*dt.  x_dev in/out, u_dev = last tick's u.
  * Asynchronous on the handle's stream. */
 int cgmres_hip_closed_loop_device(cgmres_hip_handle h, void* x_dev, void* u_dev, int32_t n_ticks);
+/* The same loop with a TIME-VARYING reference: before tick k (k = 0 .. n_ticks-1) the parameter horizon of every
+ * instance is replaced by ptau_seq[k], i.e. what a caller of the reference does by calling set_ptau (cgmres.hpp:36-39)
+ * before every control().  ptau_seq_dev is a device pointer: [n_ticks][batch][dim_p*(dv+1)] when per_instance = 1,
+ * [n_ticks][dim_p*(dv+1)] (one horizon broadcast to all instances) when per_instance = 0.  The ticks stay fused
+ * (CGMRES_HIP_TICKS_PER_LAUNCH per launch); after the call the handle keeps the last tick's ptau, as set_ptau would.
+ * With dim_p = 0 the sequence is ignored.  Asynchronous on the handle's stream. */
+int cgmres_hip_closed_loop_device_ptau(cgmres_hip_handle h, void* x_dev, void* u_dev, int32_t n_ticks,
+                                       const void* ptau_seq_dev, int per_instance);
 int cgmres_hip_synchronize(cgmres_hip_handle h);
 
 /* ---- state: the private members of Cgmres (cgmres.hpp:195-202) and Gmres (gmres.hpp:120-124) ------ */

@@ -178,3 +178,49 @@ def test_multiple_controller_device_loop_vs_oracle(orc):
         assert abs(m.t - n * m.dt) < 1e-12
         xd.free(), ud.free()
     mc.close()
+
+
+@pytest.mark.parametrize("per_instance", [True, False])
+@pytest.mark.parametrize("model,variant", [(0, 2), (1, 2), (0, 1)])
+def test_closed_loop_device_with_moving_reference(orc, model, variant, per_instance):
+    """Time-varying reference inside the fused device loop (cgmres_hip_closed_loop_device_ptau): a new parameter
+    horizon before every tick == the reference's `set_ptau` (cgmres.hpp:36-39) called before every `control()`.
+    23 ticks = two launch boundaries + a partial tail; the target ramps along the horizon AND from tick to tick."""
+    B, dv, km, n = 83, 50, 10, 23
+    x0, u0, p = orc.batch_scenario(model, B)
+    c = cg.CgmresBatch(model, batch=B, dv=dv, k_max=km, variant=variant)
+    c.set_ptau_repeat(p)
+    c.init_u0(u0)
+    c.init_u0_newton(u0, x0, p, 10)
+    npar = c.dim_p * (dv + 1)
+    stage = np.arange(dv + 1)
+    nb = B if per_instance else 1
+    seq = np.empty((n, nb, dv + 1, c.dim_p))
+    for k in range(n):
+        for i in range(nb):
+            # reference component 0 ramps with the tick and along the horizon; component 1 stays
+            seq[k, i, :, 0] = p[i, 0] * (1.0 + 0.004 * k) + 0.0007 * stage * (1 + 0.1 * (i % 5))
+            seq[k, i, :, 1] = p[i, 1]
+    seq = seq.reshape(n, nb, npar) if per_instance else seq.reshape(n, npar)
+    sd = c.device_buffer(seq.shape).upload(seq)
+    xd = c.device_buffer((B, c.dim_x)).upload(x0)
+    ud = c.device_buffer((B, c.dim_u))
+    c.closed_loop_device(xd, ud, n, sd, per_instance)
+    c.synchronize()
+    x, u = xd.download(), ud.download()
+    n_ax, _ = c.get_status()
+    # the handle keeps the last tick's horizon: one more ordinary tick must use it
+    u_next = c.control(x)
+    sample = sample_of(B, 14)
+    for i in sample:
+        r = orc.Controller(model, dv, km)
+        orc.start_controller(r, x0[i], u0[i], p[i])
+        xi = x0[i].copy()
+        for k in range(n):
+            r.set_ptau(seq[k, i] if per_instance else seq[k])
+            ui = r.control(xi)
+            xi = xi + r.plant(xi, ui) * r.dt
+        assert np.max(np.abs(u[i] - ui)) <= 1e-9 and np.max(np.abs(x[i] - xi)) <= 1e-9, (i, u[i], ui)
+        assert n_ax[i] == r.last_solve()[0]
+        assert np.max(np.abs(u_next[i] - r.control(xi))) <= 1e-9, i
+    sd.free(), xd.free(), ud.free(), c.close()
