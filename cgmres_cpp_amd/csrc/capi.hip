@@ -73,7 +73,7 @@ cgmres_hip_ctx* make_ctx(const cgmres_hip_config& cfg, int* resolved) {
   const bool f32 = cfg.dtype == CGMRES_HIP_F32;
   if (const Plugin* pl = find_plugin(cfg.model_id)) {  // user models: the lane mapping only (user_model.hip.h)
     *resolved = cfg.variant == 0 ? 1 : cfg.variant;
-    return *resolved == 1 ? pl->make(&cfg) : nullptr;
+    return *resolved == 1 ? pl->make(&cfg) : nullptr;  // (CtxLane::init records variant 1)
   }
   switch (cfg.model_id) {
     case CGMRES_HIP_MODEL_PENDULUM:
@@ -237,14 +237,13 @@ int cgmres_hip_create(const cgmres_hip_config* cfg, cgmres_hip_handle* out) {
   if (len >= 32768 || len * (cfg->k_max + 1) >= 65536)
     return fail(CGMRES_HIP_EINVAL, "dim_u*dv = %ld with k_max = %d exceeds the reference's 16-bit index range", len, cfg->k_max);
   if (!(cfg->h > 0) || !(cfg->dt > 0) || !(cfg->tol >= 0)) return fail(CGMRES_HIP_EINVAL, "h, dt must be > 0 and tol >= 0");
-  if (cfg->variant < 0 || cfg->variant > 2) return fail(CGMRES_HIP_EINVAL, "unknown variant %d", cfg->variant);
+  if (cfg->variant < 0 || cfg->variant > 3) return fail(CGMRES_HIP_EINVAL, "unknown variant %d", cfg->variant);
   if (int rc = check_device(cfg->device)) return rc;
   int resolved = 0;
   cgmres_hip_ctx* c = make_ctx(*cfg, &resolved);
   if (!c) return fail(CGMRES_HIP_EINVAL, "variant %d does not support model %d with dv = %d, k_max = %d", resolved,
                       cfg->model_id, cfg->dv, cfg->k_max);
-  c->cfg = *cfg;
-  c->cfg.variant = resolved;
+  c->cfg = *cfg;  // init() replaces cfg.variant (the request, 0 = library's choice) by the resolved mapping
   if (int rc = c->init()) {
     if (const Plugin* pl = find_plugin(cfg->model_id)) cgm::g_err = pl->last_error();  // the plugin has its own copy
     delete c;

@@ -19,6 +19,7 @@ struct CtxLane final : cgmres_hip_ctx {
 
   int init() override {
     if (int rc = init_common()) return rc;
+    cfg.variant = 1;
     nx = M::NX, nu = M::NU, np = M::NP;
     L = nu * cfg.dv;
     ldb = (cfg.batch + 63) / 64 * 64;

@@ -9,6 +9,9 @@
 namespace cgm {
 
 constexpr size_t kLdsLimit = 160 * 1024 - 1024;  // gfx950: 160 KiB per workgroup, minus the kernels' small static LDS
+// Two workgroups share a CU when each allocates at most half of the 160 KiB (measured, tools/ubench_hwid.hip: 81408
+// bytes of dynamic LDS co-reside, 81920 do not).
+constexpr size_t kLdsLimitLean = 80 * 1024 - 512;
 
 template <class T>
 __global__ void replicate_rows_im(T* __restrict__ dst, size_t dst_pitch, const T* __restrict__ src, int B, int n,
@@ -23,31 +26,50 @@ template <class M, class T>
 struct CtxWg final : cgmres_hip_ctx {
   WgParams<T> P{};
   T t = T(0);
-  int ipw = 0, maxm = 0, ks_all = 0;
-  size_t lds_bytes = 0;
+  int ipw = 0, maxm = 0, ks_all = 0, plan = PLAN_FULL;
+  size_t lds_bytes = 0, lds_bytes_hook = 0;
   void (*k_tick)(WgParams<T>) = nullptr;
   void (*k_hook)(WgParams<T>) = nullptr;
   T *stage = nullptr, *stage2 = nullptr;
   size_t stage_n = 0, stage2_n = 0;
   T *x_dev = nullptr, *u_dev = nullptr;
+  int fh_hbm_for_hooks = 0;
 
-  const char* variant_name() const override { return "wg"; }
+  const char* variant_name() const override { return plan == PLAN_LEAN ? "wg-lean" : "wg"; }
 
-  // (IPW, MAXM) instantiations: 16 or 8 instances per workgroup, vectors up to 160 or 320 elements
+  // (IPW, MAXM) instantiations: 16 or 8 instances per workgroup, vectors up to 160 or 320 elements; the lean LDS plan
+  // (two workgroups per CU) exists for 16 instances per workgroup
   template <int IPW, int MAXM>
-  void pick() {
+  void pick(bool lean) {
     k_tick = tick_wg_kernel<M, T, IPW, MAXM>;
+    if constexpr (IPW == 16) {
+      if (lean) k_tick = tick_wg_kernel<M, T, IPW, MAXM, true>;
+    }
     k_hook = hook_wg_kernel<M, T, IPW, MAXM>;
     ipw = IPW, maxm = MAXM;
+  }
+  static int pitch_H(int k_max) { return ((k_max * (k_max + 3)) / 2) | 1; }
+  // lean plan: 16 instances per workgroup in at most half a CU's LDS; the white-box hooks keep running on the full
+  // (or fh_hbm) plan of the same sizes, so that one must fit as well
+  static bool lean_supported(const cgmres_hip_config& c, size_t* bytes_out) {
+    const int L = M::NU * c.dv;
+    if (L > 320) return false;
+    const int Lp = L | 1, Pp = (M::NP * (c.dv + 1)) | 1, Hp = pitch_H(c.k_max);
+    const size_t bl = WgLds<M, T, 16>::bytes(c.dv, c.k_max, Lp, Pp, Hp, PLAN_LEAN);
+    int ipw_full;
+    size_t b_full;
+    if (bl > kLdsLimitLean || !supported(c, &ipw_full, &b_full) || ipw_full != 16) return false;
+    *bytes_out = bl;
+    return true;
   }
   // Preference: 16 instances per workgroup with everything in LDS; 16 with F(U,x+hf,t+h) in HBM (WgLds::count_T);
   // 8 instances per workgroup.
   static bool supported(const cgmres_hip_config& c, int* ipw_out, size_t* bytes_out, int* fh_hbm_out = nullptr) {
     const int L = M::NU * c.dv;
     if (L > 320) return false;
-    const int Lp = L | 1, Pp = (M::NP * (c.dv + 1)) | 1, Hp = ((c.k_max + 1) * (c.k_max + 1)) | 1;
+    const int Lp = L | 1, Pp = (M::NP * (c.dv + 1)) | 1, Hp = pitch_H(c.k_max);
     const size_t b16 = WgLds<M, T, 16>::bytes(c.dv, c.k_max, Lp, Pp, Hp);
-    const size_t b16h = WgLds<M, T, 16>::bytes(c.dv, c.k_max, Lp, Pp, Hp, 1);
+    const size_t b16h = WgLds<M, T, 16>::bytes(c.dv, c.k_max, Lp, Pp, Hp, PLAN_FH_HBM);
     const size_t b8 = WgLds<M, T, 8>::bytes(c.dv, c.k_max, Lp, Pp, Hp);
     if (fh_hbm_out) *fh_hbm_out = 0;
     if (b16 <= kLdsLimit) {
@@ -74,19 +96,42 @@ struct CtxWg final : cgmres_hip_ctx {
     int fh_hbm = 0;
     if (!supported(cfg, &want, &lds_bytes, &fh_hbm))
       return fail(CGMRES_HIP_EINVAL, "wg mapping: dim_u*dv = %d / LDS footprint not supported", L);
+    // Plan.  variant 3 asks for the lean plan; the default takes it when the batch needs more 16-instance workgroups than
+    // the GPU has CUs (two workgroups per CU then run their serial phases side by side instead of in two rounds).
+    lds_bytes_hook = lds_bytes;
+    size_t lean_bytes = 0;
+    const bool lean_ok = want == 16 && lean_supported(cfg, &lean_bytes);
+    int cus = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg.device));
+    bool lean = false;
+    if (cfg.variant == 3) {
+      if (!lean_ok) return fail(CGMRES_HIP_EINVAL, "wg-lean mapping: LDS footprint of dim_u*dv = %d, k_max = %d not supported", L, cfg.k_max);
+      lean = true;
+    } else if (cfg.variant == 0 && lean_ok && (cfg.batch + 15) / 16 > cus) {
+      lean = true;
+    }
+    if (const char* e = getenv("CGMRES_HIP_WG_PLAN")) {  // A/B switch for measurements: "lean" / "full"
+      if (!strcmp(e, "lean") && lean_ok) lean = true;
+      if (!strcmp(e, "full")) lean = false;
+    }
+    if (lean) plan = PLAN_LEAN, fh_hbm = 0, lds_bytes = lean_bytes;
+    else plan = fh_hbm ? PLAN_FH_HBM : PLAN_FULL;
+    cfg.variant = lean ? 3 : 2;
+    const int fh_hbm_hook = lean ? [&] { int i, f = 0; size_t bb; supported(cfg, &i, &bb, &f); return f; }() : fh_hbm;
     const bool big = L > 160;
-    if (want == 16 && !big) pick<16, 10>();
-    if (want == 16 && big) pick<16, 20>();
-    if (want == 8 && !big) pick<8, 10>();
-    if (want == 8 && big) pick<8, 20>();
+    if (want == 16 && !big) pick<16, 10>(lean);
+    if (want == 16 && big) pick<16, 20>(lean);
+    if (want == 8 && !big) pick<8, 10>(false);
+    if (want == 8 && big) pick<8, 20>(false);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 int(lds_bytes)));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hook), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                int(lds_bytes)));
+                                int(lds_bytes_hook)));
+    fh_hbm_for_hooks = fh_hbm_hook;
     const int k1 = cfg.k_max + 1;
     ks_all = k1 * k1 + k1 + 3 * cfg.k_max;
     P.B = cfg.batch, P.dv = cfg.dv, P.kmax = cfg.k_max, P.L = L, P.fh_hbm = fh_hbm, P.lds_bytes = int(lds_bytes);
-    P.Lp = L | 1, P.Lg = (L + 15) / 16 * 16, P.Lv = 16 * maxm, P.Pp = (np * (cfg.dv + 1)) | 1, P.Hp = (k1 * k1) | 1;
+    P.Lp = L | 1, P.Lg = (L + 15) / 16 * 16, P.Lv = 16 * maxm, P.Pp = (np * (cfg.dv + 1)) | 1, P.Hp = pitch_H(cfg.k_max);
     P.h = T(cfg.h), P.dt = T(cfg.dt), P.tol = T(cfg.tol);
     P.inv_h = T(1.0) / P.h;
     P.one_m_zh = (1 - T(cfg.zeta) * P.h);
@@ -95,7 +140,8 @@ struct CtxWg final : cgmres_hip_ctx {
     if ((rc = dalloc(&P.U, B * Lg)) || (rc = dalloc(&P.dUdt, B * Lg)) || (rc = dalloc(&P.Fh, B * Lg)) ||
         (rc = dalloc(&P.V, B * k1 * size_t(P.Lv))) || (rc = dalloc(&P.xdxh, B * nx)) ||
         (rc = dalloc(&P.ptau, B * size_t(np) * (cfg.dv + 1))) || (rc = dalloc(&P.kry, B * ks_all)) ||
-        (rc = dalloc(&P.scr, size_t((cfg.batch + ipw - 1) / ipw) * 2 * cfg.dv * WgLds<M, T, 16>::NSTG * ipw)) ||
+        (rc = dalloc(&P.scr, size_t((cfg.batch + ipw - 1) / ipw) * 2 * (cfg.dv + WgLds<M, T, 16>::TAB_PAD) * WgLds<M, T, 16>::NSTG * ipw)) ||
+        (rc = dalloc(&P.pT, lean ? size_t((cfg.batch + ipw - 1) / ipw) * (cfg.dv + 1) * (np ? np : 1) * ipw : 1)) ||
         (rc = dalloc(&P.park, maxm > 10 ? size_t((cfg.batch + ipw - 1) / ipw) * ipw * P.Lv : 1)) ||
         (rc = dalloc(&P.n_ax, B)) || (rc = dalloc(&P.reason, B)) || (rc = dalloc(&x_dev, B * nx)) ||
         (rc = dalloc(&u_dev, B * nu)))
@@ -277,7 +323,10 @@ struct CtxWg final : cgmres_hip_ctx {
     P.x_in = x ? x_dev : nullptr, P.u_out = nullptr, P.x_next = nullptr;
     P.dtau_h = dtau_of(t + P.h);
     P.dtau_0 = dtau_of(t);
-    k_hook<<<grid(), block(), lds_bytes, stream>>>(P);
+    const int keep = P.fh_hbm;
+    P.fh_hbm = fh_hbm_for_hooks, P.lds_bytes = int(lds_bytes_hook);  // the hook kernels use the full / fh_hbm plan
+    k_hook<<<grid(), block(), lds_bytes_hook, stream>>>(P);
+    P.fh_hbm = keep, P.lds_bytes = int(lds_bytes);
     HIP_TRY(hipGetLastError());
     if (out) HIP_TRY(hipMemcpyAsync(out, dout, n * sizeof(T), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));

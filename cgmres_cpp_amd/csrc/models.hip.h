@@ -292,10 +292,14 @@ struct PendulumDev {
   //   * the trig-dependent part of dxdt[3],  A32 x2^2 sin d + (A32a x2 - A32b u0) cos d + A52 sin x1  (model.hpp:41,
   //     regrouped), is one multiply per lane + a quad sum, bit-identical in the four lanes, so x stays replicated
   //     without any broadcast.
-  // Stage-table writes (all lanes, no branch): x0,x2 -> slots 0,2 (same value from every lane); this lane's x1c
-  // -> slot 1 from the x1-lanes, slot 3 from the d-lanes; the trig value -> slots 4 (sin d), 5 (cos d), 6 (cos x1)
-  // and 3 (sin x1).  Slot 3 (x3) is never read: stage_coeffs does not use x[3] because q3 = 0.
+  // Stage-table writes (all lanes, no branch), NSLOT = 6 slots per (stage, instance): x0, x1, x2 -> slots 0, 1, 2
+  // (x0, x2: the same value from every lane; x1 from the two x1-lanes), sin d, cos d, cos x1 -> slots 3, 4, 5.
+  // x3 is not stored: stage_coeffs does not use x[3] because q3 = 0.  The two values nobody needs — the d-lanes' -x1
+  // and sin x1 — go to slots 1 and 3 of the NEXT stage, where the proper lanes overwrite them one stage later (LDS
+  // operations of a wave complete in order); the table therefore has one pad stage after the last one (TAB_PAD).
   static constexpr bool HAS_QUAD_SWEEP = true;
+  static constexpr int NSLOT = 6, TRIG_SLOT0 = 3, TAB_PAD = 1;
+  static_assert(NBW <= NSLOT, "the junk redirection assumes the stage pitch is NSLOT");
   static constexpr int QSLOT_XA = 0, QSLOT_XB = 2, QLANE_TRUE_X = 2;  // write2 slots; a lane whose x[1] is +x1
   struct QuadLane {
     static constexpr int NK = Math::NK;
@@ -312,8 +316,8 @@ struct PendulumDev {
       hs = is_cos ? T(0) : T(1), hc = is_cos ? T(1) : T(0);
       mp = rho == 0 ? A32 : T(0), mq = rho == 1 ? A32a : T(0), mr = rho == 1 ? -A32b : T(0), ms = rho == 2 ? A52 : T(0);
       kap = rho < 2 ? T(1) : T(0), sg = rho < 2 ? T(-1) : T(1);
-      slot_x1 = rho < 2 ? 3 : 1;
-      slot_v = rho == 0 ? NX : (rho == 1 ? NX + 1 : (rho == 2 ? 3 : NX + 2));
+      slot_x1 = rho < 2 ? NSLOT + 1 : 1;                                                  // d-lanes: junk, next stage
+      slot_v = rho == 0 ? 3 : (rho == 1 ? 4 : (rho == 2 ? NSLOT + 3 : 5));  // sin x1: junk, next stage
     }
   };
   // this lane's trig value of `arg`; *amax accumulates max|arg| (arguments outside the fast range make the caller
@@ -421,6 +425,7 @@ struct MsdDev {
     g[5] = (u[1] - uc) * (u[1] - uc) + u[3] * u[3] - ur * ur;
   }
   static constexpr bool HAS_QUAD_SWEEP = false;  // no transcendental in the state equation: nothing to spread
+  static constexpr int NSLOT = NX + NC, TRIG_SLOT0 = NX, TAB_PAD = 0;
   // affine-in-costate split (model.hpp:50-64 regrouped): the Jacobian is constant, only qx depends on the stage
   static constexpr int NBW = 4, NUL = 2;
   static __device__ __forceinline__ void stage_coeffs(T* bw, T* phi, const T* x, const T* u, const T* p, const T*,
@@ -494,6 +499,7 @@ struct SemiactiveDev {
     g[2] = (u[0] - uc) * (u[0] - uc) + u[1] * u[1] - ur * ur;
   }
   static constexpr bool HAS_QUAD_SWEEP = false;
+  static constexpr int NSLOT = NX + NC, TRIG_SLOT0 = NX, TAB_PAD = 0;
   // affine-in-costate split (model.hpp:46-55 regrouped)
   static constexpr int NBW = 4, NUL = 1;
   static __device__ __forceinline__ void stage_coeffs(T* bw, T* phi, const T* x, const T* u, const T*, const T*,

@@ -45,8 +45,8 @@ enum WgMode { WG_TICK = 0, WG_HOOK_F = 1, WG_HOOK_PREPARE = 2, WG_HOOK_AX = 3, W
 template <class T>
 struct WgParams {
   int B, dv, kmax, L, Lp, Lg, Lv, Pp, Hp, fh_hbm, lds_bytes;  // fh_hbm: F(U,x+hf,t+h) is kept in HBM only (P.Fh), see WgLds
-   // Lp/Pp/Hp: odd LDS row pitches; Lg: global row pitch (multiple of 16);
-                                        // Lv = 16*MAXM: pitch of the Krylov rows (pads kept zero, no guards)
+   // Lp/Pp/Hp: odd LDS row pitches (Hp: the COMPACT Hessenberg, column k = k+2 entries at offset k(k+3)/2);
+   // Lg: global row pitch (multiple of 16); Lv = 16*MAXM: pitch of the Krylov rows (pads kept zero, no guards)
   T h, dt, tol, inv_h, one_m_zh, dtau_h, dtau_0;
   // closed loop on the device: up to CGM_FUSE_MAX consecutive ticks per launch, the controller state (U in LDS, dUdt
   // in registers, x in LDS) carried from tick to tick without going through HBM; dtau_tab[2*k], [2*k+1] = the two
@@ -61,7 +61,8 @@ struct WgParams {
   // instance-major HBM state
   T *U, *dUdt, *Fh, *V, *xdxh, *ptau;  // [B][Lg], [B][Lg], [B][Lg], [B][kmax+1][Lv], [B][NX], [B][NP*(dv+1)]
   T* kry;                              // [B][KS]: H (k1*k1 col-major) | rho (k1) | g (3*kmax)
-  T* scr;                              // [workgroups][2][dv*NSTG*IPW]: parked stage tables of the preamble sweeps
+  T* scr;                              // [workgroups][2][(dv+TAB_PAD)*NSTG*IPW]: parked stage tables of the preamble sweeps
+  T* pT;                               // lean plan: [workgroups][(dv+1)*NP][IPW] parameter horizon, transposed
   T* park;                             // [workgroups*IPW][Lv]: the solution vector during the Arnoldi loop (MAXM > 10 only)
   int *n_ax, *reason;
   const T* x_in;  // [B][NX]
@@ -101,49 +102,66 @@ __device__ __forceinline__ void cgm_stamp(int id) {
 #endif
 
 // ---- LDS carve-up -------------------------------------------------------------------------------
+// Three plans (WgParams::fh_hbm selects between the first two at run time, LEAN is a kernel template parameter):
+//   full    U, F(U,x+hf,t+h) and the work vector W as rows, the stage table, ptau, the small Krylov arrays
+//   fh_hbm  the row array of F(U,x+hf,t+h) is left out — the coefficient phase, its only reader after the preamble,
+//           takes it from HBM (P.Fh).  Used when that is what lets 16 instances fit (MSD at N = 50: L = 300).
+//   lean    only W, the stage table and the small arrays: U lives in the row lanes' REGISTERS (and is published into W
+//           for the two unperturbed sweeps of the preamble), F(U,x+hf,t+h) and ptau are read from HBM/L2 by the
+//           coefficient phase.  Half the footprint: TWO workgroups share a CU (<= 79.5 KB each), and the hardware
+//           places their sweep waves on different SIMDs (tools/ubench_hwid.hip) — the serial phases of 32 instances
+//           per CU overlap.  Chosen when a batch needs more workgroups than the GPU has CUs, or when controllers of
+//           two models share the GPU (multiple_controller).
+enum WgPlan { PLAN_FULL = 0, PLAN_FH_HBM = 1, PLAN_LEAN = 2 };
 template <class M, class T, int IPW>
 struct WgLds {
-  // stage table: NSTG values per (stage, instance), layout [stage][slot][IPW]
-  //   after phase 1: slots 0..NX-1 = x(s), NX..NX+NC-1 = trig(s);  after phase 2: slots 0..NBW-1 = costate coefficients
-  static constexpr int NSTG = (M::NX + M::NC) > M::NBW ? (M::NX + M::NC) : M::NBW;
-  T *U, *Fh, *W, *R, *p, *H, *rho, *g, *xs, *xh, *xT;  // xT: terminal state of the last state sweep
+  // stage table: NSTG values per (stage, instance), layout [stage][slot][IPW], dv + TAB_PAD stages
+  //   after phase 1: slots 0..NSLOT-1 = x(s), trig(s) (model's slot map);  after phase 2: slots 0..NBW-1 = costate coefficients
+  static constexpr int NSTG = M::NSLOT > M::NBW ? M::NSLOT : M::NBW;
+  static constexpr int TAB_PAD = M::TAB_PAD;
+  T *U, *Fh, *W, *R, *p, *H, *rho, *g, *xs, *xh, *xT, *u0;  // xT: terminal states of the state sweeps in flight
   int *flag, *reason, *nax, *ksolve;
-  // fh_hbm: the row array of F(U, x+hf, t+h) is left out of LDS — the coefficient phase, its only reader after the
-  // preamble, takes it from HBM (P.Fh).  Used when that is what lets 16 instances fit (MSD at N = 50: L = 300).
-  static __host__ __device__ size_t count_T(int dv, int kmax, int Lp, int Pp, int Hp, int fh_hbm = 0) {
+  static __host__ __device__ size_t tab_count(int dv) { return size_t(dv + TAB_PAD) * NSTG * IPW; }
+  static __host__ __device__ size_t count_T(int dv, int kmax, int Lp, int Pp, int Hp, int plan = PLAN_FULL) {
     const int k1 = kmax + 1;
-    return size_t(fh_hbm ? 2 : 3) * IPW * Lp + size_t(dv) * NSTG * IPW + size_t(IPW) * Pp + size_t(IPW) * Hp + size_t(IPW) * k1 +
-           size_t(IPW) * 3 * kmax + size_t(5) * M::NX * IPW;
+    const int rows = plan == PLAN_FULL ? 3 : (plan == PLAN_FH_HBM ? 2 : 1);
+    return size_t(rows) * IPW * Lp + tab_count(dv) + (plan == PLAN_LEAN ? 0 : size_t(IPW) * Pp) + size_t(IPW) * Hp +
+           size_t(IPW) * k1 + size_t(IPW) * 3 * kmax + size_t(plan == PLAN_LEAN ? 4 : 5) * M::NX * IPW +
+           (plan == PLAN_LEAN ? size_t(M::NU) * IPW : 0);
   }
-  static __host__ __device__ size_t bytes(int dv, int kmax, int Lp, int Pp, int Hp, int fh_hbm = 0) {
-    return count_T(dv, kmax, Lp, Pp, Hp, fh_hbm) * sizeof(T) + 4 * IPW * sizeof(int) + 16;
+  static __host__ __device__ size_t bytes(int dv, int kmax, int Lp, int Pp, int Hp, int plan = PLAN_FULL) {
+    return count_T(dv, kmax, Lp, Pp, Hp, plan) * sizeof(T) + 4 * IPW * sizeof(int) + 16;
   }
-  __device__ __forceinline__ WgLds(unsigned char* base, const WgParams<T>& P, bool fh_hbm) {
+  __device__ __forceinline__ WgLds(unsigned char* base, const WgParams<T>& P, int plan) {
     T* q = reinterpret_cast<T*>(base);
     const int k1 = P.kmax + 1;
-    U = q, q += IPW * P.Lp;
-    Fh = q, q += fh_hbm ? 0 : IPW * P.Lp;  // fh_hbm: Fh aliases W (the preamble moves the result to HBM)
+    const bool lean = plan == PLAN_LEAN;
+    U = q, q += lean ? 0 : IPW * P.Lp;                 // lean: U aliases W (never dereferenced as U)
+    Fh = q, q += plan == PLAN_FULL ? IPW * P.Lp : 0;  // otherwise Fh aliases W (the preamble moves the result to HBM)
     W = q, q += IPW * P.Lp;
-    R = q, q += P.dv * NSTG * IPW;
-    p = q, q += IPW * P.Pp;
+    R = q, q += tab_count(P.dv);
+    p = q, q += lean ? 0 : IPW * P.Pp;
     H = q, q += IPW * P.Hp;
     rho = q, q += IPW * k1;
     g = q, q += IPW * 3 * P.kmax;
     xs = q, q += M::NX * IPW;
     xh = q, q += M::NX * IPW;
-    xT = q, q += 3 * M::NX * IPW;  // three terminal states: the preamble sweeps run concurrently
+    xT = q, q += (lean ? 2 : 3) * M::NX * IPW;  // full plans: three concurrent preamble sweeps, lean: two
+    u0 = q, q += lean ? M::NU * IPW : 0;        // lean: the control of the current tick for the plant step
     int* z = reinterpret_cast<int*>(q);
     flag = z, reason = z + IPW, nax = z + 2 * IPW, ksolve = z + 3 * IPW;
   }
 };
 
 // Per-thread view of one workgroup's job.
-template <class M, class T, int IPW, int MAXM>
+template <class M, class T, int IPW, int MAXM, bool LEAN = false>
 struct WgCtx {
   using Lds = WgLds<M, T, IPW>;
   static constexpr int NSTG = Lds::NSTG;
   const WgParams<T>& P;
   Lds S;
+  T ureg[LEAN ? MAXM : 1];  // lean plan: this row's U, in the row layout, for the whole launch
+  T* pTw;                   // lean plan: this workgroup's transposed parameter horizon [(stage*NP + j)*IPW + i]
   int tid, inst, r, b;  // b = global instance of this thread's row
   bool valid;           // row has a real instance
   bool sweep_lane;      // this thread runs the serial sweeps (for instance `tid`)
@@ -152,7 +170,9 @@ struct WgCtx {
   typename M::Math mc;  // per-thread math context (pinned sin/cos constants); A/B: keeping it live for the whole
                         // kernel is 13 us/tick FASTER than re-creating it inside every sweep
   __device__ __forceinline__ WgCtx(const WgParams<T>& P_, unsigned char* smem)
-      : P(P_), S(smem, P_, MAXM > 10 && P_.fh_hbm), tid(threadIdx.x), inst(threadIdx.x >> 4), r(threadIdx.x & 15) {
+      : P(P_), S(smem, P_, LEAN ? PLAN_LEAN : (MAXM > 10 && P_.fh_hbm ? PLAN_FH_HBM : PLAN_FULL)), tid(threadIdx.x),
+        inst(threadIdx.x >> 4), r(threadIdx.x & 15) {
+    pTw = LEAN ? P.pT + size_t(blockIdx.x) * (P.dv + 1) * (M::NP > 0 ? M::NP : 1) * IPW : nullptr;
     b = blockIdx.x * IPW + inst;
     valid = b < P.B;
     bi = blockIdx.x * IPW + tid;
@@ -198,12 +218,16 @@ struct WgCtx {
   __device__ __forceinline__ void publish_direction(const T* reg) const {
     T uu[MAXM];  // all reads first (pad lanes read in-bounds words of the next row, never stored)
 #pragma unroll
-    for (int m = 0; m < MAXM; ++m) uu[m] = S.U[inst * P.Lp + elem(m)];
+    for (int m = 0; m < MAXM; ++m) uu[m] = LEAN ? ureg[m] : S.U[inst * P.Lp + elem(m)];
 #pragma unroll
     for (int m = 0; m < MAXM; ++m) {
       const int e = elem(m);
       if (e < P.L) S.W[inst * P.Lp + e] = reg[m] * P.h + uu[m];
     }
+  }
+  // lean plan: the unperturbed sweeps read U through W as well
+  __device__ __forceinline__ void publish_U() const {
+    if constexpr (LEAN) reg_to_lds(S.W, ureg);
   }
   __device__ __forceinline__ void reg_to_row(T* g, size_t pitch, const T* reg) const {
     if (!valid) return;
@@ -241,13 +265,23 @@ struct WgCtx {
     for (int m = 0; m < MAXM; m += 2) q[(m / 2) * 16] = Pair{reg[m], reg[m + 1]};
   }
 
+  // element q of this row's parameter horizon: LDS row, or (lean) the workgroup's transposed copy in HBM/L2, which the
+  // coefficient phase reads 16 instances at a time.  Readers are other waves of this workgroup = same CU, same L1:
+  // visible after a barrier that drains vmcnt (__syncthreads), like the parked stage tables.
+  __device__ __forceinline__ void put_p(int q, T v) const {
+    if constexpr (LEAN)
+      pTw[size_t(q) * IPW + inst] = v;
+    else
+      S.p[inst * P.Pp + q] = v;
+  }
+  __device__ __forceinline__ T get_p(int i, int q) const { return LEAN ? pTw[size_t(q) * IPW + i] : S.p[i * P.Pp + q]; }
   // Common prologue: U, ptau -> LDS; x -> LDS (component-major); flags cleared.  All global loads of the row are
   // issued before the first LDS store so they overlap (one HBM/L2 round trip instead of one per element).
   __device__ __forceinline__ void load_common(const T* Ug) {
     constexpr int PMAX = 8;  // ptau entries per lane held in flight (covers dim_p*(dv+1) <= 128)
     const int np_all = M::NP * (P.dv + 1);
-    T ureg[MAXM], preg[PMAX], xreg = T(0);
-    load_row_to_reg(ureg, Ug, P.Lg);
+    T urow[MAXM], preg[PMAX], xreg = T(0);
+    load_row_to_reg(urow, Ug, P.Lg);
     if (valid) {
 #pragma unroll
       for (int n = 0; n < PMAX; ++n) {
@@ -256,14 +290,18 @@ struct WgCtx {
       }
       if (r < M::NX && P.x_in) xreg = P.x_in[size_t(b) * M::NX + r];
     }
+    if constexpr (LEAN) {
+#pragma unroll
+      for (int m = 0; m < MAXM; ++m) ureg[m] = urow[m];
+    }
     if (valid) {
-      reg_to_lds(S.U, ureg);
+      if constexpr (!LEAN) reg_to_lds(S.U, urow);
 #pragma unroll
       for (int n = 0; n < PMAX; ++n) {
         const int q = r + 16 * n;
-        if (q < np_all) S.p[inst * P.Pp + q] = preg[n];
+        if (q < np_all) put_p(q, preg[n]);
       }
-      for (int q = r + 16 * PMAX; q < np_all; q += 16) S.p[inst * P.Pp + q] = P.ptau[size_t(b) * np_all + q];
+      for (int q = r + 16 * PMAX; q < np_all; q += 16) put_p(q, P.ptau[size_t(b) * np_all + q]);
       if (r < M::NX) S.xs[r * IPW + inst] = xreg;
     }
     if (r == 0) {
@@ -279,7 +317,7 @@ struct WgCtx {
     if (!valid) return;
     const int np_all = M::NP * (P.dv + 1);
     const T* src = seq_tick + size_t(b) * P.pseq_inst;
-    for (int q = r; q < np_all; q += 16) S.p[inst * P.Pp + q] = src[q];
+    for (int q = r; q < np_all; q += 16) put_p(q, src[q]);
   }
 
   // ---- horizon sweep (cgmres.hpp:113-162; with PERT also :168-169, with MODE the post-processing) ------------
@@ -292,7 +330,7 @@ struct WgCtx {
 
   // The Fh-in-HBM mode only exists in the long-vector instantiations (L > 160 is where LDS gets tight); the short ones
   // compile it out, so the headline kernel carries none of its branches.
-  __device__ __forceinline__ bool fh_hbm() const { return MAXM > 10 && P.fh_hbm; }
+  __device__ __forceinline__ bool fh_hbm() const { return LEAN || (MAXM > 10 && P.fh_hbm); }
   // value of lane `src` (a lane of this wave) through the LDS crossbar
   static __device__ __forceinline__ double row_bcast(double v, int src) {
     const int lo = __builtin_amdgcn_ds_bpermute(src * 4, __double2loint(v));
@@ -329,7 +367,7 @@ struct WgCtx {
       const bool goq = lt < 4 * IPW && blockIdx.x * IPW + qi < P.B && (!only_active || S.flag[qi]);
       typename M::QuadLane Q;
       Q.init(rho, mc);
-      const T* __restrict__ U = (PERT ? S.W : S.U) + qi * P.Lp;  // PERT: W holds U + h*direction (publish_direction)
+      const T* __restrict__ U = (PERT || LEAN ? S.W : S.U) + qi * P.Lp;  // PERT: W holds U + h*direction (publish_direction)
       const T dtau1 = Q.sg * dtau;
       T x[NX], v = T(0), amax = T(0);
       if (goq) {
@@ -398,7 +436,7 @@ struct WgCtx {
     } else {
       const int i = lt;
       const bool go = i < IPW && blockIdx.x * IPW + i < P.B && (!only_active || S.flag[i]);
-      const T* __restrict__ U = (PERT ? S.W : S.U) + i * P.Lp;
+      const T* __restrict__ U = (PERT || LEAN ? S.W : S.U) + i * P.Lp;  // (lean: W holds U for the unperturbed sweeps)
       T* __restrict__ R = tab + i;
       T xs[NX];
       if (go) {
@@ -423,7 +461,7 @@ struct WgCtx {
         for (int c = 0; c < NX; ++c) q[c * IPW] = xs[c];
         M::dxdt(f, xs, a.v, tr, mc);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) q[(NX + c) * IPW] = tr[c];
+        for (int c = 0; c < NC; ++c) q[(M::TRIG_SLOT0 + c) * IPW] = tr[c];
 #pragma unroll
         for (int c = 0; c < NX; ++c) xs[c] = f[c] * dtau + xs[c];
       };
@@ -465,11 +503,11 @@ struct WgCtx {
 #pragma unroll
     for (int c = 0; c < NX; ++c) x[c] = Rs[c * IPW];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) tr[c] = Rs[(NX + c) * IPW];
+    for (int c = 0; c < NC; ++c) tr[c] = Rs[(M::TRIG_SLOT0 + c) * IPW];
 #pragma unroll
-    for (int j = 0; j < NU; ++j) u[j] = (PERT ? S.W : S.U)[i * P.Lp + s * NU + j];
+    for (int j = 0; j < NU; ++j) u[j] = (PERT || LEAN ? S.W : S.U)[i * P.Lp + s * NU + j];
 #pragma unroll
-    for (int j = 0; j < NP; ++j) p[j] = S.p[i * P.Pp + s * NP + j];
+    for (int j = 0; j < NP; ++j) p[j] = get_p(i, s * NP + j);
     M::stage_coeffs(bw, phi, x, u, p, tr, dtau);
     // coefficients go back pair-interleaved — pair c of instance i at [(c*IPW + i)*2, +1] of the stage's region —
     // so the costate sweep fetches them with 16-byte LDS reads (ds_read_b128: 8 cycles; ds_read2_b64: 16).  In place
@@ -538,7 +576,7 @@ struct WgCtx {
 #pragma unroll
     for (int c = 0; c < NX; ++c) xs[c] = xT[c * IPW + i];
 #pragma unroll
-    for (int j = 0; j < NP; ++j) p[j] = S.p[i * P.Pp + dv * NP + j];
+    for (int j = 0; j < NP; ++j) p[j] = get_p(i, dv * NP + j);
     M::dPhidx(l, xs, p);
     // One wave issues one instruction per ~4.4 cycles whatever it is (tools/ubench_issue.hip), so the loop is written
     // for instruction count: moving pointers with immediate offsets, no branch inside a trip, unconditional
@@ -655,7 +693,7 @@ struct WgCtx {
 #pragma unroll
     for (int c = 0; c < NX; ++c) x[c] = S.xs[c * IPW + i];
 #pragma unroll
-    for (int j = 0; j < M::NU; ++j) u0[j] = S.U[i * P.Lp + j];
+    for (int j = 0; j < M::NU; ++j) u0[j] = (LEAN ? S.W : S.U)[i * P.Lp + j];  // (lean: call after publish_U)
     M::dxdt(f, x, u0, tr, mc);
 #pragma unroll
     for (int c = 0; c < NX; ++c) S.xh[c * IPW + i] = f[c] * P.h + x[c];
@@ -670,10 +708,56 @@ struct WgCtx {
   // COLLECTIVE; needs at least 3 waves (falls back to sequential sweeps otherwise).
   template <bool WITH_AX0>
   __device__ __forceinline__ void preamble(T* bb, T* ax0, const T* dir = nullptr) {  // dir: registers of the W direction
+    if constexpr (LEAN) {
+      // Lean plan: W is the only row array.  #1 and #2 read the unperturbed U through it (state sweeps concurrently on
+      // waves 0/1, then their coefficient/costate phases one after the other, U re-published in between because the
+      // results pass through W), #3 follows as an ordinary pipelined sweep on W = U + h*dUdt: one serial sweep more
+      // than the full plans, the price of fitting two workgroups on a CU.
+      static_assert(IPW * 16 >= 128, "lean preamble: two sweep waves");
+      T* tab0 = P.scr + size_t(blockIdx.x) * 2 * Lds::tab_count(P.dv);
+      T* xT0 = S.xT, *xT1 = S.xT + M::NX * IPW;
+      publish_U();
+      __syncthreads();
+      make_xh();
+      __syncthreads();
+      sweep_state<false, false>(0, S.xh, dtau_h, S.R, xT0, false);
+      sweep_state<false, false>(64, S.xs, dtau_0, tab0, xT1, false);
+      __threadfence_block();
+      __syncthreads();  // drains vmcnt: the parked table is complete and visible to the other waves of this CU
+      CGM_STAMP(*this, 4);
+      sweep_coeffs<false, F_PLAIN>(dtau_h, S.R, S.W, false);  // in place: every entry of W is read (as u) before it is written
+      __syncthreads();
+      sweep_costate<F_PLAIN>(dtau_h, xT0, S.W, false);
+      __syncthreads();
+      {
+        T fh[MAXM];
+        lds_to_reg(fh, S.W);
+        reg_to_row(P.Fh, P.Lg, fh);
+      }
+      __threadfence_block();
+      __syncthreads();  // F(U,x+hf,t+h) rows visible to the coefficient phases of this CU; W is free again
+      publish_U();
+      __syncthreads();
+      sweep_coeffs<false, F_RHS>(dtau_0, tab0, S.W, false);
+      __syncthreads();
+      sweep_costate<F_RHS>(dtau_0, xT1, S.W, false);
+      __syncthreads();
+      lds_to_reg(bb, S.W);
+      __syncthreads();
+      if (WITH_AX0) {
+        publish_direction(dir);
+        __syncthreads();
+        f_eval<true, F_AX>(S.xh, dtau_h, S.W, false);
+        __syncthreads();
+        lds_to_reg(ax0, S.W);
+        __syncthreads();
+      }
+      return;
+    }
     make_xh();
     __syncthreads();
     if constexpr (IPW * 16 >= 192) {
-      const size_t tab_n = size_t(P.dv) * NSTG * IPW;
+      const size_t tab_n = Lds::tab_count(P.dv);
       T* tab0 = P.scr + size_t(blockIdx.x) * 2 * tab_n;
       T* tab1 = tab0 + tab_n;
       T* xT0 = S.xT, *xT1 = S.xT + M::NX * IPW, *xT2 = S.xT + 2 * M::NX * IPW;
@@ -743,7 +827,8 @@ struct WgCtx {
   // Out: xv updated.  All threads of the block must call this (it contains workgroup barriers).
   __device__ __forceinline__ void gmres(T* xv, const T* bb, const T* ax0) {
     const int kmax = P.kmax, k1 = kmax + 1;
-    T* Hi = S.H + inst * P.Hp;
+    T* Hi = S.H + inst * P.Hp;  // compact: column k has k+2 entries (rows 0..k+1) at offset k(k+3)/2
+    auto hoff = [](int k) { return (k * (k + 3)) >> 1; };
     T* rhoi = S.rho + inst * k1;
     T* gi = S.g + inst * 3 * kmax;
     T vcur[MAXM], w[MAXM];
@@ -825,7 +910,7 @@ struct WgCtx {
       ax(true, request_rows);  // :48  W <- A v_k, in place
       if (active) {
         lds_to_reg(w, S.W);
-        T* Hk = Hi + k1 * k;
+        T* Hk = Hi + hoff(k);
         // modified Gram-Schmidt, gmres.hpp:52-58, in order; v_k itself is still in registers
         auto mgs_round = [&](const T* vi, int i) {
           T pa = 0, pb = 0;  // two partial sums: the fp64 FMA chain is latency-bound (8 cycles/op dependent)
@@ -955,7 +1040,8 @@ struct WgCtx {
         T e = r < ks ? rhoi[r] : T(0);
         const int row_lane0 = (threadIdx.x & 63) & ~15;
         for (int i = ks - 1; i >= 0; --i) {
-          const T hii = Hi[k1 * i + i], hji = Hi[k1 * i + r];  // r <= 15 stays inside H (k1*k1 words, i < k1-1)
+          // (r > i + 1 reads words of the following columns / arrays: in bounds, only used where r < i)
+          const T hii = Hi[hoff(i) + i], hji = Hi[hoff(i) + r];
           const T y = e / hii;                                   // meaningful in lane i
           const T yi = row_bcast(y, row_lane0 + i);
           e = r < i ? e - hji * yi : (r == i ? y : e);
@@ -965,8 +1051,8 @@ struct WgCtx {
       } else if (r == 0) {
         for (int i = ks - 1; i >= 0; --i) {
           T ei = rhoi[i];
-          for (int j = ks - 1; j > i; --j) ei -= Hi[k1 * j + i] * rhoi[j];
-          rhoi[i] = ei / Hi[k1 * i + i];
+          for (int j = ks - 1; j > i; --j) ei -= Hi[hoff(j) + i] * rhoi[j];
+          rhoi[i] = ei / Hi[hoff(i) + i];
         }
         S.ksolve[inst] = ks;
       }
@@ -1014,8 +1100,11 @@ struct WgCtx {
     if (!valid) return;
     const int kmax = P.kmax, k1 = kmax + 1, ks_all = k1 * k1 + k1 + 3 * kmax;
     T* dst = P.kry + size_t(b) * ks_all;
-    const T* Hi = S.H + inst * P.Hp;
-    for (int q = r; q < k1 * k1; q += 16) dst[q] = Hi[q];
+    const T* Hi = S.H + inst * P.Hp;  // compact columns -> the reference's (k_max+1) x (k_max+1) column-major array
+    for (int q = r; q < k1 * k1; q += 16) {
+      const int col = q / k1, row = q - col * k1;
+      dst[q] = (col < kmax && row <= col + 1) ? Hi[((col * (col + 3)) >> 1) + row] : T(0);
+    }
     for (int q = r; q < k1; q += 16) dst[k1 * k1 + q] = S.rho[inst * k1 + q];
     for (int q = r; q < 3 * kmax; q += 16) dst[k1 * k1 + k1 + q] = S.g[inst * 3 * kmax + q];
     if (r == 0) {
@@ -1026,10 +1115,11 @@ struct WgCtx {
 };
 
 // ---- the tick kernel: cgmres.hpp:78-110 for IPW instances ----------------------------------------
-template <class M, class T, int IPW, int MAXM>
-__global__ __launch_bounds__(IPW * 16) __attribute__((amdgpu_waves_per_eu(1, 1))) void tick_wg_kernel(WgParams<T> P) {
+template <class M, class T, int IPW, int MAXM, bool LEAN = false>
+__global__ __launch_bounds__(IPW * 16) __attribute__((amdgpu_waves_per_eu(LEAN ? 2 : 1, LEAN ? 2 : 1))) void tick_wg_kernel(
+    WgParams<T> P) {
   extern __shared__ __align__(16) unsigned char smem[];
-  WgCtx<M, T, IPW, MAXM> C(P, smem);
+  WgCtx<M, T, IPW, MAXM, LEAN> C(P, smem);
   T du[MAXM], bb[MAXM];
   C.load_common(P.U);
   C.load_row_to_reg(du, P.dUdt, P.Lg);
@@ -1040,9 +1130,9 @@ __global__ __launch_bounds__(IPW * 16) __attribute__((amdgpu_waves_per_eu(1, 1))
     // H region zeroed so the exported Hessenberg has no stale entries
     for (int q = C.r; q < P.Hp; q += 16) C.S.H[C.inst * P.Hp + q] = T(0);
     if (M::NP > 0 && P.ptau_seq) C.load_ptau_tick(P.ptau_seq + size_t(tk) * P.pseq_tick);
-    __syncthreads();
+    __syncthreads();  // (also drains the prologue's / load_ptau_tick's HBM stores of the lean parameter table)
     CGM_STAMP(C, 0);
-    C.publish_direction(du);  // direction of the first mat-vec: x0 = dUdt (warm start, cgmres.hpp:99)
+    if constexpr (!LEAN) C.publish_direction(du);  // direction of the first mat-vec: x0 = dUdt (warm start, cgmres.hpp:99)
     T ax0[MAXM];
     C.template preamble<true>(bb, ax0, du);  // Fh in LDS (or HBM); b and A*dUdt in registers
     CGM_STAMP(C, 1);
@@ -1050,7 +1140,12 @@ __global__ __launch_bounds__(IPW * 16) __attribute__((amdgpu_waves_per_eu(1, 1))
     CGM_STAMP(C, 12);
     // U += dUdt*dt, u = U[0:dim_u]  (cgmres.hpp:102-109)
     T un[MAXM];
-    C.lds_to_reg(un, C.S.U);
+    if constexpr (LEAN) {
+#pragma unroll
+      for (int m = 0; m < MAXM; ++m) un[m] = C.ureg[m];
+    } else {
+      C.lds_to_reg(un, C.S.U);
+    }
 #pragma unroll
     for (int m = 0; m < MAXM; ++m) un[m] = un[m] + du[m] * P.dt;
     if (last) {  // the controller state goes back to HBM with the last tick of the launch only
@@ -1067,7 +1162,14 @@ __global__ __launch_bounds__(IPW * 16) __attribute__((amdgpu_waves_per_eu(1, 1))
       }
       if (C.valid && C.r < M::NX) P.xdxh[size_t(C.b) * M::NX + C.r] = C.S.xh[C.r * IPW + C.inst];
     }
-    C.reg_to_lds(C.S.U, un);  // the plant step and the next tick read U from LDS
+    // the plant step and the next tick read the new U: from LDS, or (lean) from the row registers + a small u array
+    if constexpr (LEAN) {
+#pragma unroll
+      for (int m = 0; m < MAXM; ++m) C.ureg[m] = un[m];
+      if (C.valid && C.r < M::NU) C.S.u0[C.r * IPW + C.inst] = un[0];
+    } else {
+      C.reg_to_lds(C.S.U, un);
+    }
     if (P.x_next) {  // plant step of the example main loop (<example>/main.cpp:71-73)
       __syncthreads();
       if (C.sweep_lane) {
@@ -1076,7 +1178,7 @@ __global__ __launch_bounds__(IPW * 16) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
         for (int c = 0; c < M::NX; ++c) x[c] = C.S.xs[c * IPW + i];
 #pragma unroll
-        for (int j = 0; j < M::NU; ++j) u[j] = C.S.U[i * P.Lp + j];
+        for (int j = 0; j < M::NU; ++j) u[j] = LEAN ? C.S.u0[j * IPW + i] : C.S.U[i * P.Lp + j];
         M::dxdt(f, x, u, tr, C.mc);
 #pragma unroll
         for (int c = 0; c < M::NX; ++c) {

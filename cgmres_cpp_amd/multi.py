@@ -3,8 +3,10 @@ reference's multiple_controller example (multiple_controller/main.cpp:89-118: tw
 types, `controller1.control(u1,x1); controller2.control(u2,x2);` back to back, one timer around both).
 
 Each member batch has its own handle and HIP stream, so the tick kernels of the different models overlap on the
-device; `control_device` enqueues all of them and `synchronize` joins them."""
-from . import CgmresBatch
+device; `control_device` enqueues all of them and `synchronize` joins them.  Members are created on the "wg-lean"
+mapping (variant 3: half a CU's LDS per workgroup) where their sizes allow it, so workgroups of DIFFERENT members
+share a CU and the models really run side by side instead of taking turns on the CUs."""
+from . import CgmresBatch, CgmresHipError
 
 
 class MultipleController:
@@ -17,6 +19,12 @@ class MultipleController:
             kw.setdefault("device", device)
             if streams is not None:
                 kw["stream"] = streams[i]
+            if len(specs) > 1 and "variant" not in kw:
+                try:
+                    self.members.append(CgmresBatch(variant=3, **kw))
+                    continue
+                except CgmresHipError:
+                    pass  # sizes outside the lean plan: the library's default mapping
             self.members.append(CgmresBatch(**kw))
 
     def __len__(self):

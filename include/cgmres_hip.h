@@ -73,8 +73,9 @@ typedef struct cgmres_hip_config {
   int32_t dv;          /* Model::dv    horizon stages */
   int32_t k_max;       /* Model::k_max GMRES iterations */
   int32_t device;      /* HIP device ordinal */
-  int32_t variant;     /* kernel mapping: 0 = library default, 1 = "lane", 2 = "wg" (DESIGN.md); get_config
-                          returns the resolved value */
+  int32_t variant;     /* kernel mapping: 0 = library's choice, 1 = "lane", 2 = "wg" (one workgroup per CU: everything
+                          of 16 instances in LDS), 3 = "wg-lean" (half the LDS, two workgroups per CU);
+                          get_config returns the resolved value */
   double tol;          /* Model::tol */
   double dt;           /* Model::dt   sampling period */
   double h;            /* Model::h    forward-difference step */

@@ -116,3 +116,30 @@ def test_unmodified_reference_main_runs_on_gpu(tmp_path):
     u = _read_traj(tmp_path / "arm_type_inverted_pendulum_u.txt")
     assert u.shape[0] == 10001
     assert np.max(np.abs(u[:101, 1:] - g["loop_u"][:101])) <= 1.5e-6
+
+
+def test_standalone_gmres_is_a_compile_time_error(tmp_path):
+    """The facade keeps `class Gmres` (reference include/gmres.hpp:8-129) for code that names it, but a subclass that
+    CALLS the protected host solver gmres(x, b) (gmres.hpp:28) is rejected by the compiler with an explanatory
+    message — no run-time abort, no silent CPU path.  Deriving and overriding Ax_func alone still compiles."""
+    inc = os.path.join(ROOT, "include")
+    ok = tmp_path / "ok.cpp"
+    ok.write_text('''
+#include "gmres.hpp"
+struct Mine : Gmres {
+  Mine() : Gmres(4, 2, 1e-6) {}
+  void Ax_func(double* Ax, const double* x) override { for (int i = 0; i < 4; ++i) Ax[i] = 2.0 * x[i]; }
+};
+int main() { Mine m; (void)m; return 0; }
+''')
+    bad = tmp_path / "bad.cpp"
+    bad.write_text(ok.read_text().replace("int main()", "struct Calls : Mine { void go(double* x, const double* b) { gmres(x, b); } };\nint main()")
+                   .replace("Mine m; (void)m;", "Calls c; double x[4] = {0}, b[4] = {1, 1, 1, 1}; c.go(x, b);"))
+    for cxx in ("g++", "/opt/rocm/bin/amdclang++"):
+        if not (os.path.isabs(cxx) and not os.path.exists(cxx)):
+            r = subprocess.run([cxx, "-std=c++17", "-I", inc, "-c", "-o", str(tmp_path / "ok.o"), str(ok)],
+                               capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+            r = subprocess.run([cxx, "-std=c++17", "-O1", "-I", inc, "-c", "-o", str(tmp_path / "bad.o"), str(bad)],
+                               capture_output=True, text=True)
+            assert r.returncode != 0 and "stand-alone host solver is not part of the MI355X path" in r.stderr, r.stderr

@@ -24,7 +24,12 @@ CASES = {
     "msd_B4096_fh_hbm_fixedk": (1, 50, 10, 0.0, "f64", 4096, 2),
     "semiactive_B4096": (2, 50, 10, 1e-6, "f64", 4096, 2),          # BASELINE configs[2]
     "semiactive_B4096_fixedk": (2, 50, 10, 0.0, "f64", 4096, 2),
-    "pendulum_f32_N100_k20_B8192": (0, 100, 20, 1e-6, "f32", 8192, 2),  # configs[4] per-GPU share
+    "pendulum_f32_N100_k20_B8192": (0, 100, 20, 1e-6, "f32", 8192, 2),  # configs[4] per-GPU share, one workgroup per CU
+    "pendulum_f32_N100_k20_B8192_lean": (0, 100, 20, 1e-6, "f32", 8192, 3),  # ... and as the library runs it by default
+    "pendulum_B4096_lean": (0, 50, 10, 1e-6, "f64", 4096, 3),       # the lean LDS plan (two workgroups per CU): configs[3]
+    "pendulum_B4096_lean_fixedk": (0, 50, 10, 0.0, "f64", 4096, 3),
+    "msd_B4096_lean": (1, 50, 10, 1e-6, "f64", 4096, 3),            # members, MultipleController's mapping
+    "semiactive_B8192_lean": (2, 50, 10, 1e-6, "f64", 8192, 3),
     "pendulum_B200_lane": (0, 50, 10, 1e-6, "f64", 200, 1),         # the lane mapping: one tick per launch
     "msd_dv20_k5_B33": (1, 20, 5, 1e-6, "f64", 33, 2),              # ragged batch, shipped-size MSD (IPW rows unused)
 }
@@ -181,7 +186,7 @@ def test_multiple_controller_device_loop_vs_oracle(orc):
 
 
 @pytest.mark.parametrize("per_instance", [True, False])
-@pytest.mark.parametrize("model,variant", [(0, 2), (1, 2), (0, 1)])
+@pytest.mark.parametrize("model,variant", [(0, 2), (1, 2), (0, 1), (0, 3), (1, 3)])
 def test_closed_loop_device_with_moving_reference(orc, model, variant, per_instance):
     """Time-varying reference inside the fused device loop (cgmres_hip_closed_loop_device_ptau): a new parameter
     horizon before every tick == the reference's `set_ptau` (cgmres.hpp:36-39) called before every `control()`.

@@ -48,43 +48,48 @@ def remarks(rp):
 
 
 def scan(body):
-    """per-loop and total counts of scratch and AGPR-copy instructions"""
-    tot = dict(n=0, scratch=0, acc=0)
-    loops, cur = [], None
-    depth_re = re.compile(r"Loop Header: Depth=(\d+)|in Loop: Header=BB\d+_(\d+) Depth=(\d+)")
+    """Counts of scratch and AGPR-copy instructions per loop nest level.
+    The tick kernel is one big loop over the fused ticks (depth 1); depth 2 = code that runs once per Arnoldi
+    iteration (Gram-Schmidt rounds, Hessenberg column) and the stage loops of the preamble; depth >= 3 = the stage
+    loops inside the Arnoldi loop (the critical path).  Loops that contain v_trig_preop_f64 are the library-sincos
+    redo of a chunk (arguments outside the fast trig range): counted separately as `slow`."""
+    blocks, cur = [], None
     for line in body.split("\n"):
         t = line.strip()
-        mm = re.match(r"^(\.LBB\d+_\d+):\s*(;.*)?$", t)
+        mm = re.match(r"^(\.LBB\d+_\d+):", t)
         if mm:
-            if cur and cur["loop"]:
-                loops.append(cur)
-            note = mm.group(2) or ""
-            cur = dict(label=mm.group(1), loop=("Loop" in note), depth=0, n=0, scratch=0, acc=0, vmem=0, ds=0, valu=0)
+            cur = dict(label=mm.group(1)[2:], header=None, depth=0, ops=[])
+            blocks.append(cur)
             continue
-        if cur is not None and t.startswith(";") and ("Loop Header" in t or "in Loop" in t or "Inner Loop" in t):
-            cur["loop"] = True
-            d = depth_re.search(t)
+        if cur is None:
+            continue
+        if t.startswith(";"):
+            d = re.search(r"Loop Header: Depth=(\d+)", t)
             if d:
-                cur["depth"] = int(d.group(1) or d.group(3))
+                cur["header"], cur["depth"] = cur["label"], max(cur["depth"], int(d.group(1)))
+            d = re.search(r"in Loop: Header=(BB\d+_\d+) Depth=(\d+)", t)
+            if d and int(d.group(2)) >= cur["depth"]:
+                cur["header"], cur["depth"] = d.group(1), int(d.group(2))
             continue
-        if not t or t.startswith((";", ".")):
+        if not t or t.startswith("."):
             continue
-        op = t.split()[0]
-        tot["n"] += 1
-        sc = op.startswith("scratch_")
-        ac = op.startswith("v_accvgpr")
-        tot["scratch"] += sc
-        tot["acc"] += ac
-        if cur is not None:
-            cur["n"] += 1
-            cur["scratch"] += sc
-            cur["acc"] += ac
-            cur["vmem"] += op.startswith(("global_", "buffer_", "flat_"))
-            cur["ds"] += op.startswith("ds_")
-            cur["valu"] += op.startswith("v_")
-    if cur and cur["loop"]:
-        loops.append(cur)
-    return tot, loops
+        cur["ops"].append(t.split()[0])
+    slow_headers = {b["header"] for b in blocks if b["header"] and any(o == "v_trig_preop_f64" for o in b["ops"])}
+    levels = {k: dict(n=0, scratch=0, acc=0) for k in ("tick", "iter", "stage", "slow", "outside")}
+    loops = {}
+    for b in blocks:
+        key = ("slow" if b["header"] in slow_headers else
+               "outside" if b["depth"] == 0 else "tick" if b["depth"] == 1 else "iter" if b["depth"] == 2 else "stage")
+        sc = sum(o.startswith("scratch_") for o in b["ops"])
+        ac = sum(o.startswith("v_accvgpr") for o in b["ops"])
+        lv = levels[key]
+        lv["n"] += len(b["ops"]); lv["scratch"] += sc; lv["acc"] += ac
+        if key == "stage":
+            l = loops.setdefault(b["header"], dict(n=0, scratch=0, acc=0, ds=0, vmem=0))
+            l["n"] += len(b["ops"]); l["scratch"] += sc; l["acc"] += ac
+            l["ds"] += sum(o.startswith("ds_") for o in b["ops"])
+            l["vmem"] += sum(o.startswith(("global_", "buffer_", "flat_")) for o in b["ops"])
+    return levels, loops
 
 
 EXTRA = []
@@ -106,10 +111,14 @@ def main():
     with ThreadPoolExecutor(min(6, len(os.sched_getaffinity(0)))) as ex:
         res = list(ex.map(compile_tu, srcs))
     lines = ["# ISA summary of the tick kernels (gfx950, hipcc -O3; generated by tools/isa_summary.py)", "",
-             "scratch = scratch_load/store instructions, acc = v_accvgpr_read/write (VGPR<->AGPR copies: one issue slot each).",
-             "`in loops` counts only instructions inside compiler-marked loop blocks (stage loops, reflector/back-substitution loops).", "",
-             "| kernel | VGPR | AGPR | SGPR | VGPR spill | SGPR spill | scratch B/lane | instrs | scratch ops (in loops) | acc copies (in loops) |",
-             "|---|---|---|---|---|---|---|---|---|---|"]
+             "Per kernel: registers and spill counts from the compiler remarks, then WHERE scratch_load/store instructions and",
+             "VGPR<->AGPR copies (v_accvgpr_*, one issue slot each) sit, by loop nest level: `stage` = the stage loops inside the",
+             "Arnoldi loop (state / coefficient / costate sweeps: the critical path), `iter` = once per Arnoldi iteration",
+             "(Gram-Schmidt rounds, Hessenberg column) and the preamble's stage loops, `tick` = once per control tick,",
+             "`slow` = the library-sincos redo of a chunk of stages (arguments beyond the fast trig range; never taken in the benchmarks).",
+             "Entries are `scratch/acc` instruction counts (static).", "",
+             "| kernel | VGPR | AGPR | VGPR spill | SGPR spill | scratch B/lane | instrs | stage | iter | tick | slow |",
+             "|---|---|---|---|---|---|---|---|---|---|---|"]
     detail = []
     for (asm, rp), src in zip(res, srcs):
         rm = remarks(rp)
@@ -119,18 +128,18 @@ def main():
             name = m.group(1)
             if pat not in name:
                 continue
-            tot, loops = scan(m.group(0))
+            lv, loops = scan(m.group(0))
             r = rm.get(name, {})
             short = re.sub(r"cgm::|void |\(cgm::WgParams<\w+>\)|\(cgm::LaneParams<\w+>\)", "", dm.get(name, name))
-            ls, la = sum(l["scratch"] for l in loops), sum(l["acc"] for l in loops)
-            lines.append(f"| `{short}` | {r.get('vgpr')} | {r.get('agpr')} | {r.get('sgpr')} | {r.get('vgpr_spill')} | "
-                         f"{r.get('sgpr_spill')} | {r.get('scratch')} | {tot['n']} | {tot['scratch']} ({ls}) | {tot['acc']} ({la}) |")
-            hot = [l for l in loops if l["scratch"] or l["acc"]]
+            cell = lambda k: f"{lv[k]['scratch']}/{lv[k]['acc']}"
+            lines.append(f"| `{short}` | {r.get('vgpr')} | {r.get('agpr')} | {r.get('vgpr_spill')} | {r.get('sgpr_spill')} | "
+                         f"{r.get('scratch')} | {sum(v['n'] for v in lv.values())} | {cell('stage')} | {cell('iter')} | "
+                         f"{cell('tick')} | {cell('slow')} |")
+            hot = {h: l for h, l in loops.items() if l["scratch"] or l["acc"]}
             if hot:
-                detail.append(f"\n`{short}` — loop blocks with scratch / AGPR copies:")
-                for l in hot:
-                    detail.append(f"  * {l['label']} depth {l['depth']}: {l['n']} instrs (valu {l['valu']}, ds {l['ds']}, vmem {l['vmem']}), "
-                                  f"scratch {l['scratch']}, acc {l['acc']}")
+                detail.append(f"\n`{short}` — stage loops with scratch / AGPR copies: " +
+                              "; ".join(f"{h}: {l['n']} instrs (ds {l['ds']}, vmem {l['vmem']}) scratch {l['scratch']} acc {l['acc']}"
+                                        for h, l in hot.items()))
     text = "\n".join(lines + [""] + detail) + "\n"
     if out_path:
         open(os.path.join(ROOT, out_path) if not os.path.isabs(out_path) else out_path, "w").write(text)
