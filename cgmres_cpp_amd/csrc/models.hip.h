@@ -92,6 +92,17 @@ struct NoConsts {
   __device__ __forceinline__ void init() {}
 };
 
+// The library sin/cos (Payne-Hanek reduction, ~150 instructions and a few dozen live registers) is only ever reached
+// through rarely-taken branches — arguments beyond the fast range.  Kept out of line: inlined into every sweep it
+// raises the register pressure of blocks that never run, and the allocator then spills values that live across
+// them (sweep constants, rows held in registers) everywhere, which the 256-register lean kernels pay for on the
+// critical path.
+#ifdef CGM_AB_INLINE_SINCOS
+__device__ __forceinline__ void sincos_library(double a, double* sn, double* cs) { ::sincos(a, sn, cs); }
+#else
+__device__ __attribute__((noinline)) void sincos_library(double a, double* sn, double* cs) { ::sincos(a, sn, cs); }
+#endif
+
 struct SinCosKernel {
   double r, z, ps, pc;
   int q;
@@ -122,8 +133,8 @@ __device__ __forceinline__ void sincos2_f64(double a0, double a1, double* s0, do
                                             const TrigConsts& K) {
   const bool bad = !(__builtin_fabs(a0) < 1.0e5) || !(__builtin_fabs(a1) < 1.0e5);  // also catches NaN
   if (__builtin_expect(__any(bad), 0)) {
-    ::sincos(a0, s0, c0);
-    ::sincos(a1, s1, c1);
+    sincos_library(a0, s0, c0);
+    sincos_library(a1, s1, c1);
     return;
   }
   SinCosKernel k0, k1;
@@ -326,7 +337,7 @@ struct PendulumDev {
   static __device__ __forceinline__ T quad_trig(T arg, const QuadLane& Q, const Math& mc, T* amax) {
     if constexpr (SLOW) {
       double sn, cs;
-      ::sincos(double(arg), &sn, &cs);
+      sincos_library(double(arg), &sn, &cs);
       return Q.is_cos ? T(cs) : T(sn);
     } else {
       constexpr int NK = QuadLane::NK;

@@ -363,7 +363,12 @@ struct WgCtx {
     if (lt < 0 || lt >= 64) return;
     if constexpr (M::HAS_QUAD_SWEEP) {
       // four lanes (one DPP quad) per instance — see PendulumDev::quad_stage
-      const int qi = lt >> 2, rho = lt & 3;
+      const int qi = lt >> 2;
+      int rho = lt & 3;
+      // Lean plan (256 registers per wave): keep the per-lane kernel coefficients from being hoisted to the kernel
+      // entry — live across the whole tick they get spilled and every chunk of every sweep starts by waiting for
+      // their scratch reloads (+5 k cycles per sweep); made opaque here they are ~12 selects per sweep call.
+      if constexpr (LEAN) asm volatile("" : "+v"(rho));
       const bool goq = lt < 4 * IPW && blockIdx.x * IPW + qi < P.B && (!only_active || S.flag[qi]);
       typename M::QuadLane Q;
       Q.init(rho, mc);
@@ -494,8 +499,32 @@ struct WgCtx {
 
   // phase 2: costate-free part of one backward stage of one instance.
   // Reads x/trig from `tab`, writes the coefficients to S.R and the costate-free part of the result to `out`.
+  // Operands of an item that live in HBM/L2 — the parameter horizon in the lean plan, F(U,x+hf,t+h) with fh_hbm —
+  // are fetched for a whole group of items BEFORE the group is processed (and, behind the state sweep, before the
+  // barrier that releases the chunk): an item-by-item fetch exposes two dependent HBM/L2 round trips per item and
+  // the coefficient waves then fall behind the sweep wave (measured: +20 % on every sweep).
+  static constexpr bool HBM_OPERANDS = LEAN || MAXM > 10;  // kernels that carry the fh_hbm / lean code
+  static constexpr int COEFF_GROUP = sizeof(T) == 8 ? 2 : 3;
+  struct CoeffPre {
+    T p[M::NP > 0 ? M::NP : 1], fh[M::NU];
+  };
+  template <int MODE>
+  __device__ __forceinline__ void coeff_prefetch(CoeffPre& c, int s, int i) const {
+    if constexpr (LEAN) {
+#pragma unroll
+      for (int j = 0; j < M::NP; ++j) c.p[j] = pTw[size_t(s * M::NP + j) * IPW + i];
+    }
+    if (MODE != F_PLAIN && fh_hbm()) {
+      // explicitly global: left generic, hipcc merges this pointer with an LDS one and trips over the flat
+      // aperture cast ("Illegal instruction detected ... $src_shared_base", ROCm 7.2)
+      typedef const T __attribute__((address_space(1))) * GPtr;
+      const GPtr row = reinterpret_cast<GPtr>(reinterpret_cast<uintptr_t>(P.Fh)) + size_t(blockIdx.x * IPW + i) * P.Lg + s * M::NU;
+#pragma unroll
+      for (int j = 0; j < M::NU; ++j) c.fh[j] = row[j];
+    }
+  }
   template <bool PERT, int MODE>
-  __device__ __forceinline__ void coeff_item(int s, int i, T dtau, const T* tab, T* out) {
+  __device__ __forceinline__ void coeff_item(int s, int i, T dtau, const T* tab, T* out, const CoeffPre* pre = nullptr) {
     constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC, NBW = M::NBW;
     const T sc_phi = MODE == F_RHS ? P.one_m_zh : T(1.0);
     T x[NX], tr[NC > 0 ? NC : 1], u[NU], p[NP > 0 ? NP : 1], bw[NBW], phi[NU];
@@ -507,7 +536,7 @@ struct WgCtx {
 #pragma unroll
     for (int j = 0; j < NU; ++j) u[j] = (PERT || LEAN ? S.W : S.U)[i * P.Lp + s * NU + j];
 #pragma unroll
-    for (int j = 0; j < NP; ++j) p[j] = get_p(i, s * NP + j);
+    for (int j = 0; j < NP; ++j) p[j] = (LEAN && pre) ? pre->p[j] : get_p(i, s * NP + j);
     M::stage_coeffs(bw, phi, x, u, p, tr, dtau);
     // coefficients go back pair-interleaved — pair c of instance i at [(c*IPW + i)*2, +1] of the stage's region —
     // so the costate sweep fetches them with 16-byte LDS reads (ds_read_b128: 8 cycles; ds_read2_b64: 16).  In place
@@ -525,12 +554,12 @@ struct WgCtx {
       if (MODE != F_PLAIN) {
         // two loads from two address spaces, selected by VALUE (a select of the pointers would have to go through
         // the flat aperture); with fh_hbm the LDS word read is a word of W and is not used
-        T fh = S.Fh[i * P.Lp + s * NU + j];
-        if (fh_hbm()) {
-          // explicitly global: left generic, hipcc merges this pointer with the LDS one and trips over the flat
-          // aperture cast ("Illegal instruction detected ... $src_shared_base", ROCm 7.2)
-          typedef const T __attribute__((address_space(1))) * GPtr;
-          fh = reinterpret_cast<GPtr>(reinterpret_cast<uintptr_t>(P.Fh))[size_t(blockIdx.x * IPW + i) * P.Lg + s * NU + j];
+        T fh;
+        if constexpr (LEAN) {
+          fh = pre->fh[j];
+        } else {
+          fh = S.Fh[i * P.Lp + s * NU + j];
+          if (fh_hbm()) fh = pre->fh[j];
         }
         rj = (rj * sc_phi - fh) * P.inv_h;
       }
@@ -538,13 +567,37 @@ struct WgCtx {
     }
   }
   // all threads, items (s, i) with i fastest
+  __device__ __forceinline__ bool item_on(int i, bool only_active) const {
+    return blockIdx.x * IPW + i < P.B && (!only_active || S.flag[i]);
+  }
+  // items q0, q0 + stride, ... (COEFF_GROUP of them) of the range [0, n_items), stage offset s0: fetch, `between`, compute
+  template <bool PERT, int MODE, class Between>
+  __device__ __forceinline__ void coeff_group(int q0, int stride, int n_items, int s0, T dtau, const T* tab, T* out,
+                                              bool only_active, Between&& between) {
+    CoeffPre pre[COEFF_GROUP];
+#pragma unroll
+    for (int g = 0; g < COEFF_GROUP; ++g) {
+      const int q = q0 + g * stride, i = q & (IPW - 1);
+      if (q < n_items && item_on(i, only_active)) coeff_prefetch<MODE>(pre[g], s0 + q / IPW, i);
+    }
+    between();
+#pragma unroll
+    for (int g = 0; g < COEFF_GROUP; ++g) {
+      const int q = q0 + g * stride, i = q & (IPW - 1);
+      if (q < n_items && item_on(i, only_active)) coeff_item<PERT, MODE>(s0 + q / IPW, i, dtau, tab, out, &pre[g]);
+    }
+  }
   template <bool PERT, int MODE>
   __device__ __forceinline__ void sweep_coeffs(T dtau, const T* tab, T* out, bool only_active) {
-    for (int q = tid; q < P.dv * IPW; q += IPW * 16) {
-      const int i = q & (IPW - 1), s = q / IPW;
-      if (blockIdx.x * IPW + i >= P.B) continue;
-      if (only_active && !S.flag[i]) continue;
-      coeff_item<PERT, MODE>(s, i, dtau, tab, out);
+    if constexpr (HBM_OPERANDS) {
+      for (int q0 = tid; q0 < P.dv * IPW; q0 += IPW * 16 * COEFF_GROUP)
+        coeff_group<PERT, MODE>(q0, IPW * 16, P.dv * IPW, 0, dtau, tab, out, only_active, [] {});
+    } else {
+      for (int q = tid; q < P.dv * IPW; q += IPW * 16) {
+        const int i = q & (IPW - 1), s = q / IPW;
+        if (!item_on(i, only_active)) continue;
+        coeff_item<PERT, MODE>(s, i, dtau, tab, out);
+      }
     }
   }
   // the waves other than wave 0, chunk by chunk behind sweep_state<PERT, true> (one lds_barrier() before every chunk)
@@ -554,12 +607,19 @@ struct WgCtx {
     const int dv = P.dv, CH = chunk_len(), lt = tid - 64;
     for (int s0 = 0; s0 < dv; s0 += CH) {
       const int n = dv - s0 < CH ? dv - s0 : CH;
-      lds_barrier();
-      for (int q = lt; q < n * IPW; q += NL) {
-        const int i = q & (IPW - 1), s = s0 + q / IPW;
-        if (blockIdx.x * IPW + i >= P.B) continue;
-        if (only_active && !S.flag[i]) continue;
-        coeff_item<PERT, MODE>(s, i, dtau, S.R, out);
+      if constexpr (HBM_OPERANDS) {
+        // the first group's HBM operands are requested BEFORE the barrier, i.e. while the sweep wave still works on
+        // this chunk (every thread reaches the barrier exactly once per chunk, with or without items)
+        coeff_group<PERT, MODE>(lt, NL, n * IPW, s0, dtau, S.R, out, only_active, [&] { lds_barrier(); });
+        for (int q0 = lt + NL * COEFF_GROUP; q0 < n * IPW; q0 += NL * COEFF_GROUP)
+          coeff_group<PERT, MODE>(q0, NL, n * IPW, s0, dtau, S.R, out, only_active, [] {});
+      } else {
+        lds_barrier();
+        for (int q = lt; q < n * IPW; q += NL) {
+          const int i = q & (IPW - 1), s = s0 + q / IPW;
+          if (!item_on(i, only_active)) continue;
+          coeff_item<PERT, MODE>(s, i, dtau, S.R, out);
+        }
       }
     }
   }
@@ -846,7 +906,10 @@ struct WgCtx {
   CGM_KCASE(f, 1) CGM_KCASE(f, 2) CGM_KCASE(f, 3) CGM_KCASE(f, 4) CGM_KCASE(f, 5) CGM_KCASE(f, 6) CGM_KCASE(f, 7) \
   CGM_KCASE(f, 8) CGM_KCASE(f, 9) CGM_KCASE(f, 10) CGM_KCASE(f, 11) CGM_KCASE(f, 12)
     constexpr int NBUF = MAXM <= 10 ? CGM_AB_NBUF : 2, KRING = 12;
-    const bool preload = kmax <= KRING;  // workgroup-uniform; longer bases use the plain streaming loop
+    // workgroup-uniform; longer bases use the plain streaming loop.  So does the lean plan: with 256 registers per wave the
+    // twelve straight-line copies of the rounds push everything that lives across them (U, the sweep constants) into
+    // scratch — in every block of the kernel, executed or not.
+    const bool preload = !LEAN && kmax <= KRING;
     bool active = valid;
     // Long vectors: x is not touched again before the final update (gmres.hpp:110-111), and 2*MAXM more live registers
     // push the Gram-Schmidt rounds into AGPR copies and scratch (profiles/r02_isa_summary.md).  Park it in HBM

@@ -9,14 +9,20 @@ from cgmres_cpp_amd import build as b
 
 diag = os.path.join(ROOT, "_diag")  # git-ignored, but travels with gpurun (gpurun_out/ does not)
 os.makedirs(diag, exist_ok=True)
-MODEL = "msd" if "--model=msd" in sys.argv else "pendulum"
+MODEL = "msd" if "--model=msd" in sys.argv else ("pendulum32" if "--model=pendulum32" in sys.argv else "pendulum")
+MODEL_CODE = {"pendulum": 0, "msd": 1, "pendulum32": 2}[MODEL]
+def opt(name, default):
+    for a in sys.argv:
+        if a.startswith(f"--{name}="):
+            return int(a.split("=")[1])
+    return default
 lib = os.path.join(diag, f"libcgmres_hip_stamps_{MODEL}.so")
 if "--build" in sys.argv or "--build-only" in sys.argv or not os.path.exists(lib):
     srcs, _ = b.sources()
     from concurrent.futures import ThreadPoolExecutor
     def cc(s):
         o = os.path.join(diag, os.path.basename(s)[:-4] + f"_{MODEL}.o")
-        subprocess.run([b.HIPCC] + b.CFLAGS + ["-DCGM_STAMPS", f"-DCGM_STAMPS_MODEL={1 if MODEL == 'msd' else 0}", "-c", "-o", o, s], check=True)
+        subprocess.run([b.HIPCC] + b.CFLAGS + ["-DCGM_STAMPS", f"-DCGM_STAMPS_MODEL={MODEL_CODE}", "-c", "-o", o, s], check=True)
         return o
     with ThreadPoolExecutor(8) as ex:
         objs = list(ex.map(cc, srcs))
@@ -26,9 +32,13 @@ if "--build" in sys.argv or "--build-only" in sys.argv or not os.path.exists(lib
 b.LIB_PATH = lib
 import cgmres_cpp_amd as cg
 from cgmres_cpp_amd import scenarios
-B = 4096
-x0, u0, p = scenarios.batch(MODEL, B)
-c = cg.CgmresBatch(MODEL, batch=B, dv=50, k_max=10, tol=0.0)
+B, DV, KM = opt("batch", 4096), opt("dv", 50), opt("kmax", 10)
+NAME = "pendulum" if MODEL == "pendulum32" else MODEL
+DT = "f32" if MODEL == "pendulum32" else "f64"
+x0, u0, p = scenarios.batch(NAME, B)
+c = cg.CgmresBatch(NAME, batch=B, dv=DV, k_max=KM, tol=0.0, dtype=DT)
+print("variant", c.variant, "B", B, "dv", DV, "kmax", KM, DT)
+x0, u0 = x0.astype(c.np_dtype), u0.astype(c.np_dtype)
 c.set_ptau_repeat(p); c.init_u0(u0); c.init_u0_newton(u0, x0, p, 10)
 xd = c.device_buffer(x0.shape).upload(x0); ud = c.device_buffer(u0.shape)
 c.closed_loop_device(xd, ud, 50); c.synchronize()
