@@ -97,11 +97,15 @@ struct NoConsts {
 // raises the register pressure of blocks that never run, and the allocator then spills values that live across
 // them (sweep constants, rows held in registers) everywhere, which the 256-register lean kernels pay for on the
 // critical path.
-#ifdef CGM_AB_INLINE_SINCOS
-__device__ __forceinline__ void sincos_library(double a, double* sn, double* cs) { ::sincos(a, sn, cs); }
-#else
-__device__ __attribute__((noinline)) void sincos_library(double a, double* sn, double* cs) { ::sincos(a, sn, cs); }
-#endif
+// (The one-workgroup-per-CU kernels have 512 registers and keep it inline: out of line costs them 1.5 %, measured.)
+__device__ __attribute__((noinline)) void sincos_library_outlined(double a, double* sn, double* cs) { ::sincos(a, sn, cs); }
+template <bool OUTLINE>
+__device__ __forceinline__ void sincos_library(double a, double* sn, double* cs) {
+  if constexpr (OUTLINE)
+    sincos_library_outlined(a, sn, cs);
+  else
+    ::sincos(a, sn, cs);
+}
 
 struct SinCosKernel {
   double r, z, ps, pc;
@@ -129,12 +133,13 @@ struct SinCosKernel {
 };
 
 // sin/cos of two arguments at once (the pendulum needs sin/cos of x0-x1 and of x1 in every stage)
+template <bool OUTLINE = false>
 __device__ __forceinline__ void sincos2_f64(double a0, double a1, double* s0, double* c0, double* s1, double* c1,
                                             const TrigConsts& K) {
   const bool bad = !(__builtin_fabs(a0) < 1.0e5) || !(__builtin_fabs(a1) < 1.0e5);  // also catches NaN
   if (__builtin_expect(__any(bad), 0)) {
-    sincos_library(a0, s0, c0);
-    sincos_library(a1, s1, c1);
+    sincos_library<OUTLINE>(a0, s0, c0);
+    sincos_library<OUTLINE>(a1, s1, c1);
     return;
   }
   SinCosKernel k0, k1;
@@ -162,19 +167,20 @@ __device__ __forceinline__ void sincos_f64(double a, double* sn, double* cs) {
 }
 
 // Per-scalar-type math context handed to the model functions.
-template <class T>
+template <class T, bool OUTLINE_LIB = false>  // OUTLINE_LIB: library sin/cos out of line (the 256-register lean kernels)
 struct MathCtx;
 // For the quad sweep both kernels are used in the common form  value = (1 + z*P(z)) * h,  P of NK coefficients:
 //   sin: h = r, P = S1 + S2 z + ...            cos: h = 1, P = -1/2 + C1 z + C2 z^2 + ...
 // kernel_coef(is_cos, i) is coefficient i of that P (zero-padded at the top for the shorter sin kernel);
 // fast_range is the |argument| bound of the two-constant Cody-Waite reduction.
-template <>
-struct MathCtx<double> : TrigConsts {
+template <bool OUTLINE_LIB>
+struct MathCtx<double, OUTLINE_LIB> : TrigConsts {
+  static constexpr bool OUTLINE = OUTLINE_LIB;
   static constexpr int NK = 7;
   static constexpr double fast_range = 1.0e5;
   __device__ __forceinline__ void sincos_pair(double a0, double a1, double* s0, double* c0, double* s1,
                                               double* c1) const {
-    sincos2_f64(a0, a1, s0, c0, s1, c1, *this);
+    sincos2_f64<OUTLINE_LIB>(a0, a1, s0, c0, s1, c1, *this);
   }
   __device__ __forceinline__ double kernel_coef(bool is_cos, int i) const {
     const double sk[NK] = {S1, S2, S3, S4, S5, S6, 0.0}, ck[NK] = {-0.5, C1, C2, C3, C4, C5, C6};
@@ -183,8 +189,9 @@ struct MathCtx<double> : TrigConsts {
 };
 // fp32: Cephes sinf/cosf minimax kernels on [-pi/4, pi/4] (public domain), FMA-based two-constant reduction
 // (exact product n*PIO2_HI inside the fma), |a| < 1e4.  ~1 ulp; the fp32 parity bar is 1e-4 on u.
-template <>
-struct MathCtx<float> {
+template <bool OUTLINE_LIB>
+struct MathCtx<float, OUTLINE_LIB> {
+  static constexpr bool OUTLINE = OUTLINE_LIB;
   static constexpr int NK = 4;
   static constexpr float fast_range = 1.0e4f;
   float inv_pio2, pio2_hi, pio2_lo, S1, S2, S3, C1, C2, C3;
@@ -227,7 +234,10 @@ struct PendulumDev {
 
   // trig = { sin(x0-x1), cos(x0-x1), cos(x1) }
   using Math = MathCtx<T>;
-  static __device__ __forceinline__ void dxdt(T* f, const T* x, const T* u, T* trig, const Math& mc) {  // model.hpp:37-42
+  template <bool OUTLINE_LIB>
+  using MathFor = MathCtx<T, OUTLINE_LIB>;
+  template <class MC>
+  static __device__ __forceinline__ void dxdt(T* f, const T* x, const T* u, T* trig, const MC& mc) {  // model.hpp:37-42
     T sd, cd, s1, c1;
     mc.sincos_pair(x[0] - x[1], x[1], &sd, &cd, &s1, &c1);
     trig[0] = sd;
@@ -320,7 +330,8 @@ struct PendulumDev {
     T kap, sg;                     // arg = kap*x0 + x1c, x1c = sg*x1
     bool is_cos;
     int slot_x1, slot_v;
-    __device__ __forceinline__ void init(int rho, const Math& mc) {
+    template <class MC>
+    __device__ __forceinline__ void init(int rho, const MC& mc) {
       is_cos = rho & 1;
 #pragma unroll
       for (int i = 0; i < NK; ++i) k[i] = mc.kernel_coef(is_cos, i);
@@ -333,11 +344,11 @@ struct PendulumDev {
   };
   // this lane's trig value of `arg`; *amax accumulates max|arg| (arguments outside the fast range make the caller
   // redo the sweep with SLOW = true, the library sin/cos)
-  template <bool SLOW>
-  static __device__ __forceinline__ T quad_trig(T arg, const QuadLane& Q, const Math& mc, T* amax) {
+  template <bool SLOW, class MC>
+  static __device__ __forceinline__ T quad_trig(T arg, const QuadLane& Q, const MC& mc, T* amax) {
     if constexpr (SLOW) {
       double sn, cs;
-      sincos_library(double(arg), &sn, &cs);
+      sincos_library<MC::OUTLINE>(double(arg), &sn, &cs);
       return Q.is_cos ? T(cs) : T(sn);
     } else {
       constexpr int NK = QuadLane::NK;
@@ -362,15 +373,15 @@ struct PendulumDev {
   static __device__ __forceinline__ bool quad_arg_bad(T amax) { return !(amax < T(Math::fast_range)); }
   // lane-local form of the state (x[1] <- sg*x1) and the first trig value
   static __device__ __forceinline__ T quad_arg(const T* x, const QuadLane& Q) { return fma_t(Q.kap, x[0], x[1]); }
-  template <bool SLOW>
-  static __device__ __forceinline__ T quad_begin(T* x, const QuadLane& Q, const Math& mc, T* amax) {
+  template <bool SLOW, class MC>
+  static __device__ __forceinline__ T quad_begin(T* x, const QuadLane& Q, const MC& mc, T* amax) {
     x[1] = Q.sg * x[1];
     return quad_trig<SLOW>(quad_arg(x, Q), Q, mc, amax);
   }
   // One stage: x(s), v = trig(x(s)) -> x(s+1), v = trig(x(s+1)).  dtau1 = sg*dtau.
-  template <bool SLOW>
+  template <bool SLOW, class MC>
   static __device__ __forceinline__ void quad_stage(T* x, T& v, T u0, T dtau, T dtau1, const QuadLane& Q,
-                                                    const Math& mc, T* amax) {
+                                                    const MC& mc, T* amax) {
     const T m = fma_t(fma_t(Q.mp, x[2], Q.mq), x[2], fma_t(Q.mr, u0, Q.ms));
     const T trig_sum = quad_sum(mul2(m, v));  // mul2: the same rounded product in every lane of the quad
     const T f3 = fma_t(C22, x[2] - x[3], trig_sum);
@@ -406,6 +417,8 @@ struct MsdDev {
   static constexpr T m1 = T(1.0), m2 = T(1.0), d1 = T(1.0), d2 = T(1.0), k1 = T(1.0), k2 = T(1.0);
 
   using Math = NoConsts;
+  template <bool>
+  using MathFor = NoConsts;
   static __device__ __forceinline__ void dxdt(T* f, const T* x, const T* u, T*, const Math&) {  // model.hpp:36-41
     f[0] = x[2];
     f[1] = x[3];
@@ -490,6 +503,8 @@ struct SemiactiveDev {
   static constexpr T a = T(-1.0), b = T(-1.0);  // model.hpp:85-86
 
   using Math = NoConsts;
+  template <bool>
+  using MathFor = NoConsts;
   static __device__ __forceinline__ void dxdt(T* f, const T* x, const T* u, T*, const Math&) {  // model.hpp:36-39
     f[0] = x[1];
     f[1] = a * x[0] + b * u[0] * x[1];

@@ -167,7 +167,7 @@ struct WgCtx {
   bool sweep_lane;      // this thread runs the serial sweeps (for instance `tid`)
   T dtau_h, dtau_0;     // horizon steps of the current tick: F(., t+h) and F(., t)
   int bi;               // global instance of the sweep lane
-  typename M::Math mc;  // per-thread math context (pinned sin/cos constants); A/B: keeping it live for the whole
+  typename M::template MathFor<LEAN> mc;  // per-thread math context (pinned sin/cos constants); A/B: keeping it live for the whole
                         // kernel is 13 us/tick FASTER than re-creating it inside every sweep
   __device__ __forceinline__ WgCtx(const WgParams<T>& P_, unsigned char* smem)
       : P(P_), S(smem, P_, LEAN ? PLAN_LEAN : (MAXM > 10 && P_.fh_hbm ? PLAN_FH_HBM : PLAN_FULL)), tid(threadIdx.x),

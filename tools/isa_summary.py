@@ -51,8 +51,9 @@ def scan(body):
     """Counts of scratch and AGPR-copy instructions per loop nest level.
     The tick kernel is one big loop over the fused ticks (depth 1); depth 2 = code that runs once per Arnoldi
     iteration (Gram-Schmidt rounds, Hessenberg column) and the stage loops of the preamble; depth >= 3 = the stage
-    loops inside the Arnoldi loop (the critical path).  Loops that contain v_trig_preop_f64 are the library-sincos
-    redo of a chunk (arguments outside the fast trig range): counted separately as `slow`."""
+    loops inside the Arnoldi loop (the critical path).  Loops that contain v_trig_preop_f64 (library
+    sincos inlined) or a call (library sincos out of line, lean kernels) are the redo of a chunk whose arguments left
+    the fast trig range: counted separately as `slow`."""
     blocks, cur = [], None
     for line in body.split("\n"):
         t = line.strip()
@@ -74,7 +75,8 @@ def scan(body):
         if not t or t.startswith("."):
             continue
         cur["ops"].append(t.split()[0])
-    slow_headers = {b["header"] for b in blocks if b["header"] and any(o == "v_trig_preop_f64" for o in b["ops"])}
+    slow_headers = {b["header"] for b in blocks
+                    if b["header"] and any(o in ("v_trig_preop_f64", "s_swappc_b64") for o in b["ops"])}
     levels = {k: dict(n=0, scratch=0, acc=0) for k in ("tick", "iter", "stage", "slow", "outside")}
     loops = {}
     for b in blocks:
