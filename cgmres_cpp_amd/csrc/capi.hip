@@ -71,9 +71,9 @@ int check_device(int device) {
 
 cgmres_hip_ctx* make_ctx(const cgmres_hip_config& cfg, int* resolved) {
   const bool f32 = cfg.dtype == CGMRES_HIP_F32;
-  if (const Plugin* pl = find_plugin(cfg.model_id)) {  // user models: the lane mapping only (user_model.hip.h)
-    *resolved = cfg.variant == 0 ? 1 : cfg.variant;
-    return *resolved == 1 ? pl->make(&cfg) : nullptr;  // (CtxLane::init records variant 1)
+  if (const Plugin* pl = find_plugin(cfg.model_id)) {  // user models: the plugin picks the mapping (user_model.hip.h)
+    *resolved = cfg.variant;
+    return pl->make(&cfg);
   }
   switch (cfg.model_id) {
     case CGMRES_HIP_MODEL_PENDULUM:

@@ -275,6 +275,18 @@ struct WgCtx {
       S.p[inst * P.Pp + q] = v;
   }
   __device__ __forceinline__ T get_p(int i, int q) const { return LEAN ? pTw[size_t(q) * IPW + i] : S.p[i * P.Pp + q]; }
+  // the state equation at `stage` for instance i: the built-in models ignore p; a user model compiled through the
+  // plugin path may read it (Model::dxdt(ret, x, u, p), <example>/model.hpp:36)
+  __device__ __forceinline__ void model_dxdt(T* f, const T* x, const T* u, T* tr, int i, int stage) const {
+    if constexpr (DxdtUsesP<M, T>::value) {
+      T p[M::NP > 0 ? M::NP : 1];
+#pragma unroll
+      for (int j = 0; j < M::NP; ++j) p[j] = get_p(i, stage * M::NP + j);
+      M::dxdt_p(f, x, u, p);
+    } else {
+      M::dxdt(f, x, u, tr, mc);
+    }
+  }
   // Common prologue: U, ptau -> LDS; x -> LDS (component-major); flags cleared.  All global loads of the row are
   // issued before the first LDS store so they overlap (one HBM/L2 round trip instead of one per element).
   __device__ __forceinline__ void load_common(const T* Ug) {
@@ -460,11 +472,11 @@ struct WgCtx {
 #pragma unroll
         for (int j = 0; j < M::NU_DYN; ++j) a.v[j] = q[j];
       };
-      auto stage = [&](const Uc& a, T* q) {
+      auto stage = [&](const Uc& a, T* q, int sidx) {
         T f[NX], tr[NC > 0 ? NC : 1];
 #pragma unroll
         for (int c = 0; c < NX; ++c) q[c * IPW] = xs[c];
-        M::dxdt(f, xs, a.v, tr, mc);
+        model_dxdt(f, xs, a.v, tr, i, sidx);
 #pragma unroll
         for (int c = 0; c < NC; ++c) q[(M::TRIG_SLOT0 + c) * IPW] = tr[c];
 #pragma unroll
@@ -478,13 +490,13 @@ struct WgCtx {
           int k = 0;
           for (; k + 2 <= n; k += 2) {
             fetch(ub, pu + NU);
-            stage(ua, pr);
+            stage(ua, pr, s0 + k);
             fetch(ua, pu + 2 * NU);
-            stage(ub, pr + STEP);
+            stage(ub, pr + STEP, s0 + k + 1);
             pr += 2 * STEP, pu += 2 * NU;
           }
           if (k < n) {  // odd tail (last chunk only)
-            stage(ua, pr);
+            stage(ua, pr, s0 + k);
             pr += STEP, pu += NU;
           }
         }
@@ -754,7 +766,7 @@ struct WgCtx {
     for (int c = 0; c < NX; ++c) x[c] = S.xs[c * IPW + i];
 #pragma unroll
     for (int j = 0; j < M::NU; ++j) u0[j] = (LEAN ? S.W : S.U)[i * P.Lp + j];  // (lean: call after publish_U)
-    M::dxdt(f, x, u0, tr, mc);
+    model_dxdt(f, x, u0, tr, i, 0);
 #pragma unroll
     for (int c = 0; c < NX; ++c) S.xh[c * IPW + i] = f[c] * P.h + x[c];
   }
@@ -1242,7 +1254,7 @@ __global__ __launch_bounds__(IPW * 16) __attribute__((amdgpu_waves_per_eu(LEAN ?
         for (int c = 0; c < M::NX; ++c) x[c] = C.S.xs[c * IPW + i];
 #pragma unroll
         for (int j = 0; j < M::NU; ++j) u[j] = LEAN ? C.S.u0[j * IPW + i] : C.S.U[i * P.Lp + j];
-        M::dxdt(f, x, u, tr, C.mc);
+        C.model_dxdt(f, x, u, tr, i, 0);  // the example's plant = the model's own state equation (p of stage 0)
 #pragma unroll
         for (int c = 0; c < M::NX; ++c) {
           const T xn = x[c] + f[c] * P.dt;

@@ -2,13 +2,19 @@
 // (static constexpr dim_x/dim_u/dim_p/dv/k_max/dt/h/zeta/Tf/alpha/tol + static dxdt/dPhidx/dHdx/dHdu/ddHduu with
 // the signatures of <example>/model.hpp:36-76) is compiled for the device by including its header between
 //     #pragma clang force_cuda_host_device begin / end
-// and wrapped by UserDev<Model> into the interface the "lane" mapping consumes (tick_lane.hip.h: one lane per
-// instance, reference statement order — the mapping that needs nothing but the four model functions).  The "wg"
-// mapping needs the affine costate split of a model (stage_coeffs / costate_step) and is therefore reserved to the
-// built-in models.  cgmres_cpp_amd/plugin.py generates the translation unit; cgmres_hip_register_model() loads the
-// resulting shared object into the registry of libcgmres_hip.so.  fp64 only (the reference Model concept is double).
+// and wrapped by UserDev<Model> into the interface BOTH kernel mappings consume:
+//   * "lane" (tick_lane.hip.h: one lane per instance, reference statement order) needs nothing but the model functions;
+//   * "wg" (tick_wg.hip.h) needs the backward stage split into a costate-free part and a part that is affine in the
+//     costate (stage_coeffs / costate_step).  For ANY Hamiltonian H = L + lambda^T f both dH/dx and dH/du are affine in
+//     lambda, so the split is generated here by PROBING the user's own functions: dHdx(lambda = 0) = q, dHdx(e_c) - q =
+//     column c of J^T, and the same for dH/du (phi, B^T) — NX + 1 evaluations of each per (stage, instance), done by the
+//     stage-parallel coefficient phase; what stays serial is the dense affine recurrence lambda <- (lambda + dtau q) +
+//     (dtau J^T) lambda and dF = B^T lambda.  Same mathematics as the reference's loop (cgmres.hpp:145-161), different
+//     association of the sums.
+// cgmres_cpp_amd/plugin.py generates the translation unit; cgmres_hip_register_model() loads the resulting shared
+// object into the registry of libcgmres_hip.so.  fp64 only (the reference Model concept is double).
 #pragma once
-#include "ctx_lane.hip.h"
+#include "factory_impl.hip.h"
 
 namespace cgm {
 
@@ -17,6 +23,56 @@ struct UserDev {
   static constexpr int NX = Model::dim_x, NU = Model::dim_u, NP = Model::dim_p, NC = 0, NU_DYN = Model::dim_u;
   static constexpr bool DXDT_USES_P = true;
   using Math = NoConsts;
+  template <bool>
+  using MathFor = NoConsts;
+  // ---- what the wg mapping needs (tick_wg.hip.h) ----
+  static constexpr bool HAS_QUAD_SWEEP = false;
+  static constexpr int NSLOT = NX, TRIG_SLOT0 = NX, TAB_PAD = 0;
+  static constexpr int NUL = NU;                               // every component of dH/du may depend on the costate
+  static constexpr int NBW_RAW = NX + NX * NX + NU * NX;       // dtau*q | dtau*J^T (row-major) | B^T (row-major)
+  static constexpr int NBW = NBW_RAW + (NBW_RAW & 1);          // (stored in pairs)
+  static __device__ __forceinline__ void stage_coeffs(double* bw, double* phi, const double* x, const double* u,
+                                                      const double* p, const double*, double dtau) {
+    double l[NX], q[NX], g[NX], hu[NU];
+#pragma unroll
+    for (int c = 0; c < NX; ++c) l[c] = 0.0;
+    Model::dHdx(q, x, u, p, l);    // costate-free parts
+    Model::dHdu(phi, x, u, p, l);
+#pragma unroll
+    for (int r = 0; r < NX; ++r) bw[r] = dtau * q[r];
+#pragma unroll
+    for (int c = 0; c < NX; ++c) {  // unit costates: column c of J^T and of B^T
+      l[c] = 1.0;
+      Model::dHdx(g, x, u, p, l);
+      Model::dHdu(hu, x, u, p, l);
+      l[c] = 0.0;
+#pragma unroll
+      for (int r = 0; r < NX; ++r) bw[NX + r * NX + c] = dtau * (g[r] - q[r]);
+#pragma unroll
+      for (int j = 0; j < NU; ++j) bw[NX + NX * NX + j * NX + c] = hu[j] - phi[j];
+    }
+    if (NBW != NBW_RAW) bw[NBW - 1] = 0.0;
+  }
+  // l <- l + dtau*dHdx(l) and dF = B^T l_old, from the stored coefficients
+  static __device__ __forceinline__ void costate_step(double* l, double* dF, const double* bw, double) {
+    double n[NX];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+      double a = 0.0;
+#pragma unroll
+      for (int c = 0; c < NX; ++c) a += bw[NX + NX * NX + j * NX + c] * l[c];
+      dF[j] = a;
+    }
+#pragma unroll
+    for (int r = 0; r < NX; ++r) {
+      double a = l[r] + bw[r];
+#pragma unroll
+      for (int c = 0; c < NX; ++c) a += bw[NX + r * NX + c] * l[c];
+      n[r] = a;
+    }
+#pragma unroll
+    for (int r = 0; r < NX; ++r) l[r] = n[r];
+  }
   static constexpr ModelInfo info() {
     return {NX, NU, NP, Model::dv, Model::k_max, Model::dt, Model::h, Model::zeta, Model::Tf, Model::alpha, Model::tol};
   }
@@ -65,10 +121,12 @@ __global__ void user_probe_kernel(const double* x, const double* u, const double
     tuning[0] = mi.dt, tuning[1] = mi.h, tuning[2] = mi.zeta, tuning[3] = mi.Tf, tuning[4] = mi.alpha;           \
     tuning[5] = mi.tol;                                                                                          \
   }                                                                                                              \
-  /* a CtxLane for this model, not yet initialised; nullptr for anything but fp64 */                             \
+  /* a controller batch for this model on the requested / default mapping (wg when the sizes fit its LDS plan, */ \
+  /* lane otherwise), not yet initialised; nullptr for anything but fp64 or an unsupported explicit mapping      */ \
   cgmres_hip_ctx* cgmres_hip_plugin_make(const cgmres_hip_config* cfg) {                                         \
     if (cfg->dtype != CGMRES_HIP_F64) return nullptr;                                                            \
-    return new cgm::CtxLane<cgm::UserDev<MODEL>, double>();                                                      \
+    int resolved = 0;                                                                                            \
+    return cgm::make_variant<cgm::UserDev<MODEL>, double>(*cfg, &resolved);                                      \
   }                                                                                                              \
   /* [dxdt | dPhidx | dHdx | dHdu] of the DEVICE build at one point; device pointers, one thread */              \
   int cgmres_hip_plugin_probe(const double* x, const double* u, const double* p, const double* l, double* out,   \
