@@ -73,6 +73,15 @@ __global__ void k(double* out, long long* cyc, int iters, double b, double c) {
     if (TEST == 38) asm volatile(REPT(64, "global_store_dwordx4 %1, %0, off") : : "v"(i128), "v"(gp) : "memory");
     if (TEST == 39) asm volatile(REPT(32, "global_store_dwordx2 %1, %0, off\n v_fma_f64 %2, %2, %3, %4\n v_fma_f64 %2, %2, %3, %4\n v_fma_f64 %2, %2, %3, %4") : : "v"(a), "v"(gp), "v"(d), "v"(b), "v"(c) : "memory");
     if (TEST == 40) asm volatile(REPT(64, "global_load_dwordx2 %0, %1, off") : "=v"(a) : "v"(gp) : "memory");
+    // the shape of one state-sweep stage: ~52 VALU + the stage-table stores (write2 + 2 writes), clustered or spread
+    if (TEST == 41)
+      asm volatile("ds_write2_b64 %1, %0, %0 offset1:16\n ds_write_b64 %5, %0\n ds_write_b64 %5, %0 offset:2048\n"
+                   REPT(52, "v_fma_f64 %2, %2, %3, %4") : : "v"(a), "v"(addr), "v"(d), "v"(b), "v"(c), "v"(addr2) : "memory");
+    if (TEST == 42)
+      asm volatile("ds_write2_b64 %1, %0, %0 offset1:16\n" REPT(17, "v_fma_f64 %2, %2, %3, %4") "ds_write_b64 %5, %0\n"
+                   REPT(17, "v_fma_f64 %2, %2, %3, %4") "ds_write_b64 %5, %0 offset:2048\n" REPT(18, "v_fma_f64 %2, %2, %3, %4")
+                   : : "v"(a), "v"(addr), "v"(d), "v"(b), "v"(c), "v"(addr2) : "memory");
+    if (TEST == 43) asm volatile(REPT(55, "v_fma_f64 %0, %0, %1, %2") : "+v"(a) : "v"(b), "v"(c));
     if (TEST == 29) asm volatile(REPT(64, "ds_read2_b64 %0, %1 offset1:16") : "=v"(i128) : "v"(addr) : "memory");
     if (TEST == 30) asm volatile(REPT(64, "ds_read_b64 %0, %1") : "=v"(a) : "v"(addr) : "memory");
   }
@@ -139,6 +148,9 @@ int main() {
   run<38>("global_store_dwordx4, 4 lanes/address", 64);
   run<39>("global_store_dwordx2 + 3 v_fma_f64 (per 4 instr)", 128);
   run<40>("global_load_dwordx2 back to back (L1/L2 hit)", 64);
+  run<41>("stage shape: 3 LDS stores clustered + 52 v_fma_f64", 55);
+  run<42>("stage shape: 3 LDS stores spread   + 52 v_fma_f64", 55);
+  run<43>("stage shape: 55 v_fma_f64 only", 55);
   run<29>("ds_read2_b64 back to back (no wait)", 64);
   run<30>("ds_read_b64 back to back (no wait)", 64);
   return 0;
