@@ -65,6 +65,9 @@ __device__ __forceinline__ double rint_t(double a) { return __builtin_rint(a); }
 __device__ __forceinline__ float rint_t(float a) { return __builtin_rintf(a); }
 __device__ __forceinline__ double maxabs_t(double m, double a) { return __builtin_fmax(m, __builtin_fabs(a)); }
 __device__ __forceinline__ float maxabs_t(float m, float a) { return __builtin_fmaxf(m, __builtin_fabsf(a)); }
+// ordered-as-integers view of a NON-NEGATIVE value (a running maximum without the canonicalising v_max of fmax)
+__device__ __forceinline__ int nonneg_bits(double z) { return __double2hiint(z); }
+__device__ __forceinline__ int nonneg_bits(float z) { return __float_as_int(z); }
 __device__ __forceinline__ double xor_sign(double v, int flip) {
   return __hiloint2double(__double2hiint(v) ^ flip, __double2loint(v));
 }
@@ -173,11 +176,23 @@ struct MathCtx;
 //   sin: h = r, P = S1 + S2 z + ...            cos: h = 1, P = -1/2 + C1 z + C2 z^2 + ...
 // kernel_coef(is_cos, i) is coefficient i of that P (zero-padded at the top for the shorter sin kernel);
 // fast_range is the |argument| bound of the two-constant Cody-Waite reduction.
+// Rotation step of the quad sweep (PendulumDev::quad_stage_rot): sin d = d (1 + z (RS[0] + z (RS[1] + ...))) and
+// cos d - 1 = z (RC[0] + z (RC[1] + ...)), z = d^2, Taylor coefficients, truncation < 2e-17 relative for z <= rot_zmax.
 template <bool OUTLINE_LIB>
 struct MathCtx<double, OUTLINE_LIB> : TrigConsts {
   static constexpr bool OUTLINE = OUTLINE_LIB;
   static constexpr int NK = 7;
   static constexpr double fast_range = 1.0e5;
+  static constexpr int NRS = 3, NRC = 4;
+  static constexpr double rot_zmax = 1.6e-3;  // |d| <= 0.04: d^8/9! and d^10/10! below 2e-17
+  __device__ __forceinline__ double rot_sin(int i) const {
+    const double c[NRS] = {-1.0 / 6.0, 1.0 / 120.0, -1.0 / 5040.0};
+    return c[i];
+  }
+  __device__ __forceinline__ double rot_cos(int i) const {
+    const double c[NRC] = {-0.5, 1.0 / 24.0, -1.0 / 720.0, 1.0 / 40320.0};
+    return c[i];
+  }
   __device__ __forceinline__ void sincos_pair(double a0, double a1, double* s0, double* c0, double* s1,
                                               double* c1) const {
     sincos2_f64<OUTLINE_LIB>(a0, a1, s0, c0, s1, c1, *this);
@@ -194,6 +209,16 @@ struct MathCtx<float, OUTLINE_LIB> {
   static constexpr bool OUTLINE = OUTLINE_LIB;
   static constexpr int NK = 4;
   static constexpr float fast_range = 1.0e4f;
+  static constexpr int NRS = 2, NRC = 3;
+  static constexpr float rot_zmax = 1.0e-2f;  // |d| <= 0.1: d^6/7! and d^8/8! below 3e-10
+  __device__ __forceinline__ float rot_sin(int i) const {
+    const float c[NRS] = {-1.0f / 6.0f, 1.0f / 120.0f};
+    return c[i];
+  }
+  __device__ __forceinline__ float rot_cos(int i) const {
+    const float c[NRC] = {-0.5f, 1.0f / 24.0f, -1.0f / 720.0f};
+    return c[i];
+  }
   float inv_pio2, pio2_hi, pio2_lo, S1, S2, S3, C1, C2, C3;
   __device__ __forceinline__ void init() {
     inv_pio2 = 6.36619772367581382433e-01f;
@@ -328,6 +353,8 @@ struct PendulumDev {
     T hs, hc;                      // h = hs*r + hc
     T mp, mq, mr, ms;              // weight (mp*x2 + mq)*x2 + (mr*u0 + ms) of this lane's trig value in dxdt[3]
     T kap, sg;                     // arg = kap*x0 + x1c, x1c = sg*x1
+    static constexpr int NRS = Math::NRS, NRC = Math::NRC;
+    T rs[NRS], rs1, rc[NRC];       // rotation step: sgn*sin d = d (rs1 + z (rs[0] + ...)), cos d - 1 = z (rc[0] + ...)
     bool is_cos;
     int slot_x1, slot_v;
     template <class MC>
@@ -338,6 +365,14 @@ struct PendulumDev {
       hs = is_cos ? T(0) : T(1), hc = is_cos ? T(1) : T(0);
       mp = rho == 0 ? A32 : T(0), mq = rho == 1 ? A32a : T(0), mr = rho == 1 ? -A32b : T(0), ms = rho == 2 ? A52 : T(0);
       kap = rho < 2 ? T(1) : T(0), sg = rho < 2 ? T(-1) : T(1);
+      // sin(a+d) = sin a cos d + cos a sin d on a sin lane, cos(a+d) = cos a cos d - sin a sin d on a cos lane
+      rs1 = is_cos ? T(-1) : T(1);
+#pragma unroll
+      for (int i = 0; i < NRS; ++i) rs[i] = rs1 * mc.rot_sin(i);
+#pragma unroll
+      for (int i = 0; i < NRC; ++i) rc[i] = mc.rot_cos(i);
+#pragma unroll
+      for (int i = 0; i < NRC; ++i) asm volatile("" : "+v"(rc[i]));  // kept in registers like the kernel constants
       slot_x1 = rho < 2 ? NSLOT + 1 : 1;                                                  // d-lanes: junk, next stage
       slot_v = rho == 0 ? 3 : (rho == 1 ? 4 : (rho == 2 ? NSLOT + 3 : 5));  // sin x1: junk, next stage
     }
@@ -392,6 +427,44 @@ struct PendulumDev {
     x[3] = fma_t(dtau, f3, x[3]);
     v = quad_trig<SLOW>(quad_arg(x, Q), Q, mc, amax);
   }
+  // The same stage with the trig value obtained by ROTATING the previous stage's value through the angle increment
+  // d = arg(s+1) - arg(s) (exact: both are within a factor two of each other) instead of a fresh evaluation:
+  //   v' = v + (v (cos d - 1) + v_partner (+-sin d)),   v_partner = the other kernel of this lane's angle (quad swap)
+  // 17 instructions instead of 27 (no argument reduction, no quadrant logic, two short Taylor polynomials).  Each step
+  // adds ~2 ulp of rounding; the sweep restarts from a fresh evaluation at every chunk of stages (<= 2*ceil(dv/8)), so
+  // the accumulated error stays below ~30 ulp worst case, ~6 ulp typical — 4 orders of magnitude inside the parity
+  // tolerance on u.  *zmax accumulates max d^2 (integer view): a chunk whose increments leave |d| <= sqrt(rot_zmax)
+  // is redone with fresh evaluations per stage (quad_stage<false>).
+  template <class MC>
+  static __device__ __forceinline__ void quad_stage_rot(T* x, T& v, T& argp, T u0, T dtau, T dtau1, const QuadLane& Q,
+                                                        const MC& mc, int* zmax) {
+    constexpr int NRS = QuadLane::NRS, NRC = QuadLane::NRC;
+    const T m = fma_t(fma_t(Q.mp, x[2], Q.mq), x[2], fma_t(Q.mr, u0, Q.ms));
+    const T trig_sum = quad_sum(mul2(m, v));
+    const T f3 = fma_t(C22, x[2] - x[3], trig_sum);
+    const T f2 = fma_t(-As, x[2], Bs * u0);
+    x[0] = fma_t(dtau, x[2], x[0]);
+    x[1] = fma_t(dtau1, x[3], x[1]);
+    x[2] = fma_t(dtau, f2, x[2]);
+    x[3] = fma_t(dtau, f3, x[3]);
+    const T arg = quad_arg(x, Q);
+    const T d = arg - argp;
+    argp = arg;
+    const T z = mul2(d, d);
+    const int zb = nonneg_bits(z);
+    *zmax = zb > *zmax ? zb : *zmax;
+    T ps = fma3(z, Q.rs[NRS - 1], Q.rs[NRS - 2]);
+#pragma unroll
+    for (int i = NRS - 3; i >= 0; --i) ps = fma3(z, ps, Q.rs[i]);
+    const T sd = mul2(d, fma3(z, ps, Q.rs1));  // +-sin d
+    T pc = fma3(z, Q.rc[NRC - 1], Q.rc[NRC - 2]);
+#pragma unroll
+    for (int i = NRC - 3; i >= 0; --i) pc = fma3(z, pc, Q.rc[i]);
+    const T cm1 = mul2(z, pc);                 // cos d - 1
+    const T pv = dpp_move<DPP_QUAD_SWAP1>(v);
+    v = v + fma_t(v, cm1, mul2(pv, sd));
+  }
+  static __device__ __forceinline__ bool quad_rot_bad(int zmax) { return zmax > nonneg_bits(T(Math::rot_zmax)); }
   static __device__ __forceinline__ void ddHduu(T* m, const T*, const T* u, const T*, const T*) {  // :64-76
     m[0] = r0 + 2 * u[2];
     m[1] = 0;

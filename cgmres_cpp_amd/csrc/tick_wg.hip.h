@@ -402,14 +402,27 @@ struct WgCtx {
       const T* pu = U;
       T ua = T(0);
       if (goq) ua = pu[0];
-      auto run = [&](auto slow_tag, int n) {
-        constexpr bool SLOW = decltype(slow_tag)::value;
+      // Stage modes: 0 = trig value rotated from the previous stage (PendulumDev::quad_stage_rot), 1 = fresh evaluation
+      // per stage (fast kernel), 2 = fresh evaluation with the library sin/cos.  A chunk starts in mode 0 from a fresh
+      // value and is redone in mode 1 when an angle increment left the rotation's range, in mode 2 when an argument left
+      // the fast kernel's range.
+#ifndef CGM_AB_ROT
+#define CGM_AB_ROT 1
+#endif
+      constexpr bool USE_ROT = CGM_AB_ROT != 0;
+      T argp = T(0);
+      int zmax = 0;
+      auto run = [&](auto mode_tag, int n) {
+        constexpr int MODE = decltype(mode_tag)::value;
         auto stage = [&](int o, T u0) {
           pa[o * STEP + M::QSLOT_XA * IPW] = x[0];
           pa[o * STEP + M::QSLOT_XB * IPW] = x[2];
           pb[o * STEP] = x[1];
           pv[o * STEP] = v;
-          M::template quad_stage<SLOW>(x, v, u0, dtau, dtau1, Q, mc, &amax);
+          if constexpr (MODE == 0)
+            M::quad_stage_rot(x, v, argp, u0, dtau, dtau1, Q, mc, &zmax);
+          else
+            M::template quad_stage<MODE == 2>(x, v, u0, dtau, dtau1, Q, mc, &amax);
         };
         int k = 0;
         for (; k + 2 <= n; k += 2) {
@@ -430,16 +443,33 @@ struct WgCtx {
           T xs[NX];
 #pragma unroll
           for (int c = 0; c < NX; ++c) xs[c] = x[c];
-          run(std::false_type{}, n);
-          // an argument outside the fast range of the trig kernel: redo this chunk with the library sin/cos
-          if (__builtin_expect(__any(M::quad_arg_bad(amax)), 0)) {
+          auto rewind = [&]() {
 #pragma unroll
             for (int c = 0; c < NX; ++c) x[c] = xs[c];
             pa = tab + qi + s0 * STEP, pb = pa + Q.slot_x1 * IPW, pv = pa + Q.slot_v * IPW;
             pu = U + s0 * NU;
             ua = pu[0];
+          };
+          if constexpr (USE_ROT) {
+            // the chunk starts from a fresh value (the sweep's first one comes from quad_begin)
+            if (s0 > 0) v = M::template quad_trig<false>(M::quad_arg(x, Q), Q, mc, &amax);
+            argp = M::quad_arg(x, Q);
+            run(std::integral_constant<int, 0>{}, n);
+            if (__builtin_expect(__any(M::quad_rot_bad(zmax)), 0)) {  // an angle moved too far in one stage
+              rewind();
+              v = M::template quad_trig<false>(M::quad_arg(x, Q), Q, mc, &amax);
+              run(std::integral_constant<int, 1>{}, n);
+              if (n & 1) ua = pu[0];
+            }
+            zmax = 0;
+          } else {
+            run(std::integral_constant<int, 1>{}, n);
+          }
+          // an argument outside the fast range of the trig kernel: redo this chunk with the library sin/cos
+          if (__builtin_expect(__any(M::quad_arg_bad(amax)), 0)) {
+            rewind();
             v = M::template quad_trig<true>(M::quad_arg(x, Q), Q, mc, &amax);
-            run(std::true_type{}, n);
+            run(std::integral_constant<int, 2>{}, n);
             if (n & 1) ua = pu[0];
             amax = T(0);
           }
@@ -1055,6 +1085,10 @@ struct WgCtx {
           // decision is therefore row-uniform.
           CGM_STAMP(*this, 8);
           T en;
+#ifdef CGM_AB_SKIP_HESS  /* timing experiment only (breaks the solve): how much of a tick is the Hessenberg column? */
+          en = T(1);
+          if (false)
+#endif
           {
             // The running entry stays in a register (a) and only ORIGINAL column entries / reflector words are read
             // from LDS, one step ahead: no store-to-load round trip through LDS between consecutive reflectors.

@@ -34,7 +34,7 @@ else:
             env = dict(os.environ)
             if n != "base":
                 env["CGMRES_HIP_LIB"] = os.path.join(AB, n, "lib.so")
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-ref-mode", "--steps", "150", "--warmup", "30"],
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-ref-mode", "--steps", "150", "--warmup", "30"] + os.environ.get("AB_BENCH_ARGS", "").split(),
                                env=env, capture_output=True, text=True)
             res[n].append(json.loads(r.stdout.strip().split("\n")[-1])["ms_per_step"])
     for n in names:
