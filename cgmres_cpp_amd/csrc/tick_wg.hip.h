@@ -748,13 +748,17 @@ struct WgCtx {
   // `after_sweep` runs on the sweep wave right after its state sweep, i.e. while it would otherwise wait for the other
   // waves to finish the last coefficient chunk (gmres() requests its basis rows there); the barrier that follows
   // orders LDS only so those loads stay in flight during the costate sweep.
-  template <bool PERT, int MODE, class After>
-  __device__ __forceinline__ void f_eval(const T* x0c, T dtau, T* out, bool only_active, After&& after_sweep) {
+  // `idle_work` runs on the other waves BEFORE their first chunk barrier, i.e. while they would wait for the sweep wave
+  // to finish the first chunk of stages (gmres() does the previous iteration's Hessenberg column there).
+  template <bool PERT, int MODE, class After, class Idle>
+  __device__ __forceinline__ void f_eval(const T* x0c, T dtau, T* out, bool only_active, After&& after_sweep,
+                                         Idle&& idle_work) {
     if constexpr (IPW * 16 >= 128) {
       if (tid < 64) {
         sweep_state<PERT, true>(0, x0c, dtau, S.R, S.xT, only_active);
         after_sweep();
       } else {
+        idle_work();
         coeffs_chunked<PERT, MODE>(dtau, out, only_active);
       }
       CGM_STAMP(*this, 4);
@@ -762,6 +766,7 @@ struct WgCtx {
       CGM_STAMP(*this, 5);
       sweep_costate<MODE>(dtau, S.xT, out, only_active);
     } else {
+      idle_work();
       f_eval<PERT, MODE>(x0c, dtau, out, only_active);
       if (tid < 64) after_sweep();
     }
@@ -914,15 +919,47 @@ struct WgCtx {
     }
   }
   // Ax_func in place on W (cgmres.hpp:164-175).  Collective; ends with W published.
-  template <class After>
-  __device__ __forceinline__ void ax(bool only_active, After&& after_sweep) {
+  template <class After, class Idle>
+  __device__ __forceinline__ void ax(bool only_active, After&& after_sweep, Idle&& idle_work) {
     CGM_STAMP(*this, 3);
-    f_eval<true, F_AX>(S.xh, dtau_h, S.W, only_active, after_sweep);
+    f_eval<true, F_AX>(S.xh, dtau_h, S.W, only_active, after_sweep, idle_work);
     __syncthreads();
     CGM_STAMP(*this, 6);
   }
   __device__ __forceinline__ void ax(bool only_active) {
-    ax(only_active, [] {});
+    ax(only_active, [] {}, [] {});
+  }
+
+  // Hessenberg column k of one instance: stored reflectors, new reflector, residual rotation (gmres.hpp:71-90) — scalar
+  // work on the instance's small Krylov arrays in LDS.  hn = h(k+1,k).  Returns rho_e[k+1]; `writer` lanes store.
+  __device__ __forceinline__ T hess_column(T* Hi, T* gi, T* rhoi, int k, T hn, bool writer) const {
+    T* Hk = Hi + ((k * (k + 3)) >> 1);
+    // The running entry stays in a register (a) and only ORIGINAL column entries / reflector words are read
+    // from LDS, one step ahead: no store-to-load round trip through LDS between consecutive reflectors.
+    T a = Hk[0];
+    T g0n = gi[0], g1n = gi[1], g2n = gi[2], cn = Hk[1];
+    for (int i = 0; i < k; ++i) {
+      const T g0 = g0n, g1 = g1n, g2 = g2n, c = cn;
+      g0n = gi[3 * i + 3], g1n = gi[3 * i + 4], g2n = gi[3 * i + 5], cn = Hk[i + 2];  // i+1 <= k: in range
+      const T beta = (g0 * a + g1 * c) * g2;
+      if (writer) Hk[i] = a - beta * g0;
+      a = c - beta * g1;
+    }
+    const T c = hn;
+    const T sigma = -(a < T(0.0) ? T(-1.0) : T(1.0)) * sqrt_t<T>(a * a + c * c);
+    const T g0 = a - sigma, g1 = c;
+    const T g2 = T(2.0) / (g0 * g0 + g1 * g1);
+    const T ek = rhoi[k];
+    const T beta = g0 * ek * g2;
+    const T en = -beta * g1;
+    if (writer) {
+      gi[3 * k] = g0, gi[3 * k + 1] = g1, gi[3 * k + 2] = g2;
+      Hk[k] = sigma;
+      Hk[k + 1] = T(0.0);
+      rhoi[k] = ek - beta * g0;
+      rhoi[k + 1] = en;
+    }
+    return en;
   }
 
   // Gmres::gmres (gmres.hpp:28-112).  In: x (registers `xv`), b (`bb`) and A*x0 (`ax0`), all in the row layout.
@@ -985,6 +1022,15 @@ struct WgCtx {
       }
       if (r == 0) S.flag[inst] = active ? 1 : 0;
     }
+    // Fixed-k mode (tol = 0: no residual test can succeed, every running instance does all k_max iterations): the
+    // Hessenberg column of iteration k is not needed before the final triangular solve, so it is taken off the critical
+    // path — 16 lanes of wave 1 (one per instance) do column k-1 while wave 0 runs the first chunk of sweep k, where
+    // the coefficient waves would otherwise wait; the last column is done in place.  With tol > 0 the column decides
+    // whether the next mat-vec runs at all (gmres.hpp:93-95) and stays where the reference has it.
+#ifndef CGM_AB_DEFER_HESS
+#define CGM_AB_DEFER_HESS 1
+#endif
+    const bool defer_hess = CGM_AB_DEFER_HESS && IPW * 16 >= 128 && P.tol == T(0);  // workgroup-uniform
     int k = 0;
     for (; k < kmax; ++k) {  // gmres.hpp:46
       CGM_STAMP(*this, 14);
@@ -1012,7 +1058,14 @@ struct WgCtx {
         }
       };
       if (tid >= 64) request_rows();
-      ax(true, request_rows);  // :48  W <- A v_k, in place
+      auto deferred_column = [&]() {  // column k-1 of instance j = tid-64, if iteration k-1 produced one for it
+        const int j = tid - 64;
+        if (defer_hess && k > 0 && j >= 0 && j < IPW && S.reason[j] == 0 && S.nax[j] == k) {
+          T* Hj = S.H + j * P.Hp;
+          hess_column(Hj, S.g + j * 3 * kmax, S.rho + j * k1, k - 1, Hj[hoff(k - 1) + k], true);
+        }
+      };
+      ax(true, request_rows, deferred_column);  // :48  W <- A v_k, in place
       if (active) {
         lds_to_reg(w, S.W);
         T* Hk = Hi + hoff(k);
@@ -1084,40 +1137,11 @@ struct WgCtx {
           // a wave, and LDS operations of one wave complete in order), lane 0 writes back: the convergence
           // decision is therefore row-uniform.
           CGM_STAMP(*this, 8);
-          T en;
-#ifdef CGM_AB_SKIP_HESS  /* timing experiment only (breaks the solve): how much of a tick is the Hessenberg column? */
-          en = T(1);
-          if (false)
-#endif
-          {
-            // The running entry stays in a register (a) and only ORIGINAL column entries / reflector words are read
-            // from LDS, one step ahead: no store-to-load round trip through LDS between consecutive reflectors.
-            T a = Hk[0];
-            T g0n = gi[0], g1n = gi[1], g2n = gi[2], cn = Hk[1];
-            for (int i = 0; i < k; ++i) {
-              const T g0 = g0n, g1 = g1n, g2 = g2n, c = cn;
-              g0n = gi[3 * i + 3], g1n = gi[3 * i + 4], g2n = gi[3 * i + 5], cn = Hk[i + 2];  // i+1 <= k: in range
-              const T beta = (g0 * a + g1 * c) * g2;
-              if (r == 0) Hk[i] = a - beta * g0;
-              a = c - beta * g1;
-            }
-            const T c = hn;
-            const T sigma = -(a < T(0.0) ? T(-1.0) : T(1.0)) * sqrt_t<T>(a * a + c * c);
-            const T g0 = a - sigma, g1 = c;
-            const T g2 = T(2.0) / (g0 * g0 + g1 * g1);
-            const T ek = rhoi[k];
-            const T beta = g0 * ek * g2;
-            en = -beta * g1;
-            if (r == 0) {
-              gi[3 * k] = g0, gi[3 * k + 1] = g1, gi[3 * k + 2] = g2;
-              Hk[k] = sigma;
-              Hk[k + 1] = T(0.0);
-              rhoi[k] = ek - beta * g0;
-              rhoi[k + 1] = en;
-            }
-          }
+          // (deferred in fixed-k mode, except for the last column: no sweep follows it)
+          const bool column_now = !defer_hess || k + 1 == kmax;
+          const T en = column_now ? hess_column(Hi, gi, rhoi, k, hn, r == 0) : T(1);
           CGM_STAMP(*this, 9);
-          if (abs_t(en) < P.tol) {  // :93-95 — converged: column k is NOT used by the solve
+          if (column_now && abs_t(en) < P.tol) {  // :93-95 — converged: column k is NOT used by the solve
             active = false;
             if (r == 0) {
               S.reason[inst] = 1;
