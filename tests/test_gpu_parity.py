@@ -264,6 +264,44 @@ def test_large_angles_take_the_library_trig_path(orc, variant):
     c.close()
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_fast_angular_rates_leave_the_rotation_range(orc, variant):
+    """The wg state sweep advances sin/cos by rotating the previous stage's values through the angle increment; an
+    increment beyond its range (|d| > 0.04 rad per stage) makes the sweep redo that chunk of stages with fresh
+    evaluations.  A late horizon (t = 1 s: dtau = 3.9 ms) and angular rates of tens of rad/s force that path for some
+    instances of a workgroup (the redo covers the whole workgroup) — every instance must still match the oracle."""
+    model, dv, kmax, tol, B = 0, 50, 10, 1e-6, 40
+    x0, u0, p = orc.batch_scenario(model, B)
+    x0[2, 2], x0[2, 3] = 30.0, -20.0     # |d(x0-x1)| = dtau*50 = 0.2 per stage
+    x0[9, 3] = 25.0                      # x1 alone moves 0.1 per stage
+    x0[21, 2], x0[21, 3] = -12.0, 9.0    # 0.08: beyond the range as well
+    x0[33, 2] = 8.0                      # 0.03: stays inside
+    c = cg.CgmresBatch(model, batch=B, dv=dv, k_max=kmax, tol=tol, variant=variant)
+    c.set_ptau_repeat(p)
+    c.init_u0(u0)
+    c.init_u0_newton(u0, x0, p, 10)
+    refs = _oracle_batch(orc, model, dv, kmax, tol, x0, u0, p)
+    for r in refs:                       # a late horizon from the first tick on
+        _, U_o, d_o = r.get_state()
+        r.set_state(1.0, U_o, d_o)
+    x = x0.copy()
+    for tick in range(3):
+        t_o, U_o, d_o = zip(*[r.get_state() for r in refs])
+        c.set_state(t_o[0], np.array(U_o), np.array(d_o))
+        u = c.control(x)
+        assert np.all(np.isfinite(u))
+        n_ax, _ = c.get_status()
+        _, U1, d1 = c.get_state()
+        for i, r in enumerate(refs):
+            ur = r.control(x[i])
+            scale = max(1.0, float(np.max(np.abs(ur))))
+            assert np.max(np.abs(u[i] - ur)) <= U_TOL * scale, (tick, i, u[i], ur)
+            assert dudt_close(d1[i], r.get_state()[2]), (tick, i)
+            assert n_ax[i] == r.last_solve()[0], (tick, i)
+            x[i] = x[i] + r.plant(x[i], ur) * r.dt
+    c.close()
+
+
 def test_closed_loop_device_matches_host_loop(orc):
     """closed_loop_device (plant on the GPU, device pointers) == host-driven loop with the same plant rule."""
     B, dv, km, n = 70, 50, 10, 8
