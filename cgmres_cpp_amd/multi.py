@@ -9,17 +9,29 @@ share a CU and the models really run side by side instead of taking turns on the
 from . import CgmresBatch, CgmresHipError
 
 
+def _cu_count(device):
+    try:
+        import torch
+        return int(torch.cuda.get_device_properties(device).multi_processor_count)
+    except Exception:
+        return 256  # MI355X
+
+
 class MultipleController:
     def __init__(self, specs, device=0, streams=None):
         """specs: list of dicts of CgmresBatch keyword arguments (model, batch, dv, k_max, ...).
         streams: optional list of hipStream_t values (e.g. torch.cuda.Stream().cuda_stream), one per member."""
         self.members = []
+        # Sharing CUs pays when the members together need more 16-instance workgroups than the GPU has CUs; below that
+        # every workgroup gets a CU of its own and the faster one-workgroup-per-CU mapping is kept (e.g. the 8-GPU
+        # shards of multiple_controller: 2 x 32 workgroups per GPU).
+        share_cus = len(specs) > 1 and sum(-(-int(kw.get("batch", 1)) // 16) for kw in specs) > _cu_count(device)
         for i, kw in enumerate(specs):
             kw = dict(kw)
             kw.setdefault("device", device)
             if streams is not None:
                 kw["stream"] = streams[i]
-            if len(specs) > 1 and "variant" not in kw:
+            if share_cus and "variant" not in kw:
                 try:
                     self.members.append(CgmresBatch(variant=3, **kw))
                     continue

@@ -152,14 +152,18 @@ def test_closed_loop_device_resumes_across_calls(orc):
     assert np.array_equal(a[3][0], b[3][0])
 
 
-def test_multiple_controller_device_loop_vs_oracle(orc):
+@pytest.mark.parametrize("variant", [0, 3])
+def test_multiple_controller_device_loop_vs_oracle(orc, variant):
     """BASELINE configs[3] shape on one GPU: MultipleController.closed_loop_device — a Model1 (MSD) batch and a Model2
     (pendulum) batch, each on its own stream, launches interleaved (multiple_controller/main.cpp:104-118) — for 25
     ticks, every member against the oracle's free-running loops."""
     from cgmres_cpp_amd.multi import MultipleController
     n, dv, km = 25, 50, 10
-    specs = [dict(model="msd", batch=72, dv=dv, k_max=km), dict(model="pendulum", batch=88, dv=dv, k_max=km)]
+    # variant 3 = the lean mapping MultipleController picks by itself once its members have to share CUs
+    specs = [dict(model="msd", batch=72, dv=dv, k_max=km, variant=variant),
+             dict(model="pendulum", batch=88, dv=dv, k_max=km, variant=variant)]
     mc = MultipleController(specs)
+    assert all(m.variant == (variant or 2) for m in mc.members)
     xs, us, want = [], [], []
     for m, model in zip(mc.members, (1, 0)):
         x0, u0, p = orc.batch_scenario(model, m.batch)
