@@ -160,7 +160,12 @@ struct WgCtx {
   static constexpr int NSTG = Lds::NSTG;
   const WgParams<T>& P;
   Lds S;
-  T ureg[LEAN ? MAXM : 1];  // lean plan: this row's U, in the row layout, for the whole launch
+  // lean plan: this row's U in the row layout for the whole launch — in registers, unless a row is 160 bytes per lane or
+  // more (fp64 with MAXM = 20): those kernels are register-starved at 256 registers per wave and re-read their U row
+  // from HBM/L2 where they need it (once per Arnoldi iteration, ~1/30 of the iteration's traffic)
+  static constexpr bool U_IN_REGS = LEAN && sizeof(T) * MAXM < 160;
+  static constexpr bool VK_IN_REGS = !LEAN || U_IN_REGS;  // v_k kept in registers between its creation and the next MGS
+  T ureg[U_IN_REGS ? MAXM : 1];
   T* pTw;                   // lean plan: this workgroup's transposed parameter horizon [(stage*NP + j)*IPW + i]
   int tid, inst, r, b;  // b = global instance of this thread's row
   bool valid;           // row has a real instance
@@ -217,8 +222,12 @@ struct WgCtx {
   // (cgmres.hpp:166-168 forms it in every stage); the sweep phases then read one array instead of two.
   __device__ __forceinline__ void publish_direction(const T* reg) const {
     T uu[MAXM];  // all reads first (pad lanes read in-bounds words of the next row, never stored)
+    if constexpr (LEAN) {
+      get_urow(uu);
+    } else {
 #pragma unroll
-    for (int m = 0; m < MAXM; ++m) uu[m] = LEAN ? ureg[m] : S.U[inst * P.Lp + elem(m)];
+      for (int m = 0; m < MAXM; ++m) uu[m] = S.U[inst * P.Lp + elem(m)];
+    }
 #pragma unroll
     for (int m = 0; m < MAXM; ++m) {
       const int e = elem(m);
@@ -227,7 +236,20 @@ struct WgCtx {
   }
   // lean plan: the unperturbed sweeps read U through W as well
   __device__ __forceinline__ void publish_U() const {
-    if constexpr (LEAN) reg_to_lds(S.W, ureg);
+    if constexpr (LEAN) {
+      T uu[MAXM];
+      get_urow(uu);
+      reg_to_lds(S.W, uu);
+    }
+  }
+  // lean plan: this row's U (registers, or its HBM row — written by this same thread, so program order suffices)
+  __device__ __forceinline__ void get_urow(T* dst) const {
+    if constexpr (U_IN_REGS) {
+#pragma unroll
+      for (int m = 0; m < MAXM; ++m) dst[m] = ureg[m];
+    } else {
+      load_row_to_reg(dst, P.U, P.Lg);
+    }
   }
   __device__ __forceinline__ void reg_to_row(T* g, size_t pitch, const T* reg) const {
     if (!valid) return;
@@ -293,7 +315,7 @@ struct WgCtx {
     constexpr int PMAX = 8;  // ptau entries per lane held in flight (covers dim_p*(dv+1) <= 128)
     const int np_all = M::NP * (P.dv + 1);
     T urow[MAXM], preg[PMAX], xreg = T(0);
-    load_row_to_reg(urow, Ug, P.Lg);
+    if constexpr (!LEAN || U_IN_REGS) load_row_to_reg(urow, Ug, P.Lg);
     if (valid) {
 #pragma unroll
       for (int n = 0; n < PMAX; ++n) {
@@ -302,7 +324,7 @@ struct WgCtx {
       }
       if (r < M::NX && P.x_in) xreg = P.x_in[size_t(b) * M::NX + r];
     }
-    if constexpr (LEAN) {
+    if constexpr (U_IN_REGS) {
 #pragma unroll
       for (int m = 0; m < MAXM; ++m) ureg[m] = urow[m];
     }
@@ -1098,16 +1120,19 @@ struct WgCtx {
             default: break;
           }
         } else {
+          // (register-starved lean kernels: v_k is streamed back from its row like the older ones instead of being
+          // held in registers through the whole sweep; the row was written by this same thread)
           T vi[MAXM], vn[MAXM];
-          if (k > 0) load_vec(vi, vrow(0));
-          for (int i = 0; i < k; ++i) {
-            if (i + 1 < k) load_vec(vn, vrow(i + 1));
+          const int kk = VK_IN_REGS ? k : k + 1;
+          if (kk > 0) load_vec(vi, vrow(0));
+          for (int i = 0; i < kk; ++i) {
+            if (i + 1 < kk) load_vec(vn, vrow(i + 1));
             mgs_round(vi, i);
 #pragma unroll
             for (int m = 0; m < MAXM; ++m) vi[m] = vn[m];
           }
         }
-        mgs_round(vcur, k);
+        if constexpr (VK_IN_REGS) mgs_round(vcur, k);
         T na = 0, nb = 0;
 #pragma unroll
         for (int m = 0; m < MAXM; m += 2) {
@@ -1274,15 +1299,15 @@ __global__ __launch_bounds__(IPW * 16) __attribute__((amdgpu_waves_per_eu(LEAN ?
     // U += dUdt*dt, u = U[0:dim_u]  (cgmres.hpp:102-109)
     T un[MAXM];
     if constexpr (LEAN) {
-#pragma unroll
-      for (int m = 0; m < MAXM; ++m) un[m] = C.ureg[m];
+      C.get_urow(un);
     } else {
       C.lds_to_reg(un, C.S.U);
     }
 #pragma unroll
     for (int m = 0; m < MAXM; ++m) un[m] = un[m] + du[m] * P.dt;
-    if (last) {  // the controller state goes back to HBM with the last tick of the launch only
-      C.reg_to_row(P.U, P.Lg, un);
+    constexpr bool U_ROW_IS_HBM = LEAN && !decltype(C)::U_IN_REGS;  // then every tick writes its U row
+    if (last || U_ROW_IS_HBM) C.reg_to_row(P.U, P.Lg, un);
+    if (last) {  // the rest of the controller state goes back to HBM with the last tick of the launch only
       C.reg_to_row(P.dUdt, P.Lg, du);
       if (C.valid && C.r < M::NU) P.u_out[size_t(C.b) * M::NU + C.r] = un[0];  // element e = r (m = 0), r < NU <= 16
       C.store_status();
@@ -1297,8 +1322,10 @@ __global__ __launch_bounds__(IPW * 16) __attribute__((amdgpu_waves_per_eu(LEAN ?
     }
     // the plant step and the next tick read the new U: from LDS, or (lean) from the row registers + a small u array
     if constexpr (LEAN) {
+      if constexpr (decltype(C)::U_IN_REGS) {
 #pragma unroll
-      for (int m = 0; m < MAXM; ++m) C.ureg[m] = un[m];
+        for (int m = 0; m < MAXM; ++m) C.ureg[m] = un[m];
+      }
       if (C.valid && C.r < M::NU) C.S.u0[C.r * IPW + C.inst] = un[0];
     } else {
       C.reg_to_lds(C.S.U, un);
