@@ -78,6 +78,9 @@ __device__ __forceinline__ float xor_sign(float v, int flip) { return __int_as_f
 // otherwise re-materialise every constant in every stage (22 s_mov + 12 v_mov per sincos pair).
 struct TrigConsts {
   double inv_pio2, pio2_hi, pio2_lo, S1, S2, S3, S4, S5, S6, C1, C2, C3, C4, C5, C6;
+  // PIN = false (the 256-register lean kernels): the constants stay ordinary values the compiler may re-materialise
+  // where a fresh evaluation needs them (once per chunk of stages there) instead of 30 registers live for a whole tick
+  template <bool PIN = true>
   __device__ __forceinline__ void init() {
     inv_pio2 = 6.36619772367581382433e-01;
     pio2_hi = 1.57079632673412561417e+00;  // first 33 bits of pi/2
@@ -86,9 +89,11 @@ struct TrigConsts {
     S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
     C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05;
     C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    asm volatile("" : "+v"(inv_pio2), "+v"(pio2_hi), "+v"(pio2_lo));
-    asm volatile("" : "+v"(S1), "+v"(S2), "+v"(S3), "+v"(S4), "+v"(S5), "+v"(S6));
-    asm volatile("" : "+v"(C1), "+v"(C2), "+v"(C3), "+v"(C4), "+v"(C5), "+v"(C6));
+    if constexpr (PIN) {
+      asm volatile("" : "+v"(inv_pio2), "+v"(pio2_hi), "+v"(pio2_lo));
+      asm volatile("" : "+v"(S1), "+v"(S2), "+v"(S3), "+v"(S4), "+v"(S5), "+v"(S6));
+      asm volatile("" : "+v"(C1), "+v"(C2), "+v"(C3), "+v"(C4), "+v"(C5), "+v"(C6));
+    }
   }
 };
 struct NoConsts {
@@ -185,6 +190,7 @@ struct MathCtx<double, OUTLINE_LIB> : TrigConsts {
   static constexpr double fast_range = 1.0e5;
   static constexpr int NRS = 3, NRC = 4;
   static constexpr double rot_zmax = 1.6e-3;  // |d| <= 0.04: d^8/9! and d^10/10! below 2e-17
+  __device__ __forceinline__ void init() { TrigConsts::template init<!OUTLINE_LIB>(); }
   __device__ __forceinline__ double rot_sin(int i) const {
     const double c[NRS] = {-1.0 / 6.0, 1.0 / 120.0, -1.0 / 5040.0};
     return c[i];
@@ -372,7 +378,8 @@ struct PendulumDev {
 #pragma unroll
       for (int i = 0; i < NRC; ++i) rc[i] = mc.rot_cos(i);
 #pragma unroll
-      for (int i = 0; i < NRC; ++i) asm volatile("" : "+v"(rc[i]));  // kept in registers like the kernel constants
+      for (int i = 0; i < NRC; ++i)
+        if constexpr (!MC::OUTLINE) asm volatile("" : "+v"(rc[i]));  // kept in registers like the kernel constants
       slot_x1 = rho < 2 ? NSLOT + 1 : 1;                                                  // d-lanes: junk, next stage
       slot_v = rho == 0 ? 3 : (rho == 1 ? 4 : (rho == 2 ? NSLOT + 3 : 5));  // sin x1: junk, next stage
     }

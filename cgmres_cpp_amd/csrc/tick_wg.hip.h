@@ -1019,7 +1019,7 @@ struct WgCtx {
 #ifndef CGM_AB_PARK
 #define CGM_AB_PARK 1
 #endif
-    constexpr bool PARK = MAXM > 10 && CGM_AB_PARK;
+    constexpr bool PARK = (MAXM > 10 || (LEAN && sizeof(T) == 8)) && CGM_AB_PARK;  // (lean fp64: 256 registers per wave)
     if constexpr (PARK) store_vec(park_row, xv);
     // r0 = b - A x0 ; rho = ||r0||      gmres.hpp:33-37
     {
