@@ -163,7 +163,10 @@ struct WgCtx {
   // lean plan: this row's U in the row layout for the whole launch — in registers, unless a row is 160 bytes per lane or
   // more (fp64 with MAXM = 20): those kernels are register-starved at 256 registers per wave and re-read their U row
   // from HBM/L2 where they need it (once per Arnoldi iteration, ~1/30 of the iteration's traffic)
-  static constexpr bool U_IN_REGS = LEAN && sizeof(T) * MAXM < 160;
+#ifndef CGM_AB_UREG_BYTES
+#define CGM_AB_UREG_BYTES 160
+#endif
+  static constexpr bool U_IN_REGS = LEAN && sizeof(T) * MAXM < CGM_AB_UREG_BYTES;
   static constexpr bool VK_IN_REGS = !LEAN || U_IN_REGS;  // v_k kept in registers between its creation and the next MGS
   T ureg[U_IN_REGS ? MAXM : 1];
   T* pTw;                   // lean plan: this workgroup's transposed parameter horizon [(stage*NP + j)*IPW + i]

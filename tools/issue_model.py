@@ -6,8 +6,8 @@ kind per ~4.4 cycles (tools/ubench_issue.hip).  The floor of a serial phase is t
     (instructions the critical wave executes) x 4.4 cycles,
 which is what the stage loops were written against.  This tool takes
   * the static instruction count per stage of the two stage loops inside the Arnoldi loop, from the compiled ISA
-    (state sweep: the deepest loop with v_rndne_f64 = the Cody-Waite reduction, 2 stages per trip; costate sweep: the
-    deepest loop with 16-byte LDS reads, 3 stages per trip), and
+    (state sweep: the depth-4 loop with the stage-table stores and no v_rndne_f64 = the rotation-mode stage loop, 2 stages
+    per trip; costate sweep: the depth-3 loop with 16-byte LDS reads, 3 stages per trip), and
   * the measured shader cycles per phase from a phase-stamp log (tools/phase_stamps.py, diagnostic build on the GPU),
 and writes profiles/<name>.json: per phase instructions/stage, floor cycles/stage, measured cycles/stage and their
 ratio, plus the whole-tick view (share of the tick spent in the two sweeps, the tick if both ran at their floor).
@@ -55,9 +55,14 @@ def stage_loops(asm):
         ops = [o.split()[0] for o in b["ops"]]
         if any(o == "v_trig_preop_f64" for o in ops):
             continue
-        if b["depth"] == 4 and any(o.startswith("v_rndne_f64") for o in ops):
+        if b["depth"] == 4 and sum(o.startswith("ds_write") for o in ops) >= 4 and \
+                not any(o.startswith("v_rndne_f64") for o in ops):
+            # the rotation-mode stage loop (no argument reduction); the fresh-evaluation loop (v_rndne_f64) is the fallback
             out["state"] = dict(label=b["label"], instructions_per_trip=len(ops), stages_per_trip=2,
-                                lds_ops=sum(o.startswith("ds_") for o in ops))
+                                lds_ops=sum(o.startswith("ds_") for o in ops), mode="rotation")
+        elif b["depth"] == 4 and any(o.startswith("v_rndne_f64") for o in ops) and "state" not in out:
+            out["state"] = dict(label=b["label"], instructions_per_trip=len(ops), stages_per_trip=2,
+                                lds_ops=sum(o.startswith("ds_") for o in ops), mode="fresh evaluation")
         elif b["depth"] == 3 and sum(o.startswith("ds_read_b128") for o in ops) >= 6:
             out["costate"] = dict(label=b["label"], instructions_per_trip=len(ops), stages_per_trip=3,
                                   lds_ops=sum(o.startswith("ds_") for o in ops))
