@@ -72,6 +72,11 @@ struct CtxWg final : cgmres_hip_ctx {
     const size_t b16h = WgLds<M, T, 16>::bytes(c.dv, c.k_max, Lp, Pp, Hp, PLAN_FH_HBM);
     const size_t b8 = WgLds<M, T, 8>::bytes(c.dv, c.k_max, Lp, Pp, Hp);
     if (fh_hbm_out) *fh_hbm_out = 0;
+    const char* force = getenv("CGMRES_HIP_IPW");  // measurement switch: "8" = 8 instances per workgroup where that fits
+    if (force && force[0] == '8' && b8 <= kLdsLimit) {
+      *ipw_out = 8, *bytes_out = b8;
+      return true;
+    }
     if (b16 <= kLdsLimit) {
       *ipw_out = 16, *bytes_out = b16;
       return true;

@@ -1,0 +1,29 @@
+import sys, os, numpy as np
+sys.path.insert(0, '/root/repo')
+import cgmres_cpp_amd as cg
+from oracle import orc
+B, dv, km = 1024, 50, 10
+tol = float(sys.argv[1]) if len(sys.argv) > 1 else 0.0
+warm = int(sys.argv[2]) if len(sys.argv) > 2 else 120
+NC = int(sys.argv[3]) if len(sys.argv) > 3 else 11
+x0, u0, p = orc.batch_scenario(0, B)
+c = cg.CgmresBatch(0, batch=B, dv=dv, k_max=km, tol=tol)
+c.set_ptau_repeat(p); c.init_u0(u0); c.init_u0_newton(u0, x0, p, 10)
+xd = c.device_buffer((B, 4)).upload(x0); ud = c.device_buffer((B, 3))
+c.closed_loop_device(xd, ud, warm); c.synchronize()
+t, U, d = c.get_state(); x = xd.download()
+c.closed_loop_device(xd, ud, NC); c.synchronize()
+x1, u1 = xd.download(), ud.download()
+errs = []
+for i in range(B):
+    r = orc.Controller(0, dv, km, tol)
+    r.set_ptau_repeat(p[i]); r.set_state(t, U[i], d[i])
+    xi = x[i].copy()
+    for _ in range(NC):
+        ui = r.control(xi); xi = xi + r.plant(xi, ui) * r.dt
+    errs.append((float(np.max(np.abs(u1[i] - ui))), float(np.max(np.abs(x1[i] - xi))), float(np.max(np.abs(ui))), float(np.max(np.abs(r.get_state()[2])))))
+errs = np.array(errs)
+o = np.argsort(-errs[:, 0])[:8]
+print("lib", os.environ.get("CGMRES_HIP_LIB", "default"), "tol", tol, "warm", warm)
+print("worst du:", [(int(i), f"{errs[i,0]:.2e}", f"|u|={errs[i,2]:.2f}", f"|dUdt|={errs[i,3]:.1e}") for i in o])
+print("median du", np.median(errs[:, 0]), "p99", np.quantile(errs[:, 0], 0.99), "max", errs[:, 0].max())
