@@ -330,21 +330,23 @@ def test_closed_loop_device_matches_host_loop(orc):
     xd.free(), ud.free(), a.close(), b.close()
 
 
-def test_full_size_properties(orc):
-    """BASELINE's headline size (pendulum, B=4096, dv=50, k_max=10): properties that need no full oracle run.
+@pytest.mark.parametrize("model,name", [(0, "pendulum"), (1, "msd"), (2, "semiactive")])
+def test_full_size_properties(orc, model, name):
+    """BASELINE's sizes (B = 4096, dv = 50, k_max = 10; MSD runs the fh_hbm plan of the long-vector kernel): properties
+    that need no full oracle run.
       * a sample of 48 instances spread over the batch agrees with the oracle;
       * instances with identical inputs give bit-identical outputs wherever they sit in the batch;
       * with tol=0 every instance runs exactly k_max Arnoldi iterations; the leading Krylov vectors are orthonormal."""
     B, dv, km = 4096, 50, 10
-    x0, u0, p = orc.batch_scenario(0, B)
+    x0, u0, p = orc.batch_scenario(model, B)
     x0[1000], p[1000] = x0[3], p[3]      # duplicates far apart: different waves / workgroups
     x0[4095], p[4095] = x0[3], p[3]
-    c = cg.CgmresBatch("pendulum", batch=B, dv=dv, k_max=km, tol=0.0)
+    c = cg.CgmresBatch(name, batch=B, dv=dv, k_max=km, tol=0.0)
     c.set_ptau_repeat(p)
     c.init_u0(u0)
     c.init_u0_newton(u0, x0, p, 10)
     sample = list(range(0, B, 89))[:46] + [1000, 4095]
-    refs = {i: orc.Controller(0, dv, km, 0.0) for i in sample}
+    refs = {i: orc.Controller(model, dv, km, 0.0) for i in sample}
     for i, r in refs.items():
         orc.start_controller(r, x0[i], u0[i], p[i])
     x = x0.copy()
