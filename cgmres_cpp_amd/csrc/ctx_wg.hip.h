@@ -54,6 +54,7 @@ struct CtxWg final : cgmres_hip_ctx {
   static bool lean_supported(const cgmres_hip_config& c, size_t* bytes_out) {
     const int L = M::NU * c.dv;
     if (L > 320 || DxdtUsesP<M, T>::value) return false;  // (a state equation that reads p wants the horizon in LDS)
+    if (c.dv < 5) return false;  // (the costate look-ahead below the stage table must land in the row array before it)
     const int Lp = L | 1, Pp = (M::NP * (c.dv + 1)) | 1, Hp = pitch_H(c.k_max);
     const size_t bl = WgLds<M, T, 16>::bytes(c.dv, c.k_max, Lp, Pp, Hp, PLAN_LEAN);
     int ipw_full;

@@ -136,6 +136,16 @@ struct WgLds {
     T* q = reinterpret_cast<T*>(base);
     const int k1 = P.kmax + 1;
     const bool lean = plan == PLAN_LEAN;
+    // The costate sweep's look-ahead reads up to two stages BELOW the start of its operand arrays (values never used):
+    // below the stage table that is a row array, below the first row of `out` it is whatever precedes the row arrays.
+    // In the full plans U / Fh precede W; in the lean plan W would be the first array of the allocation, so the small
+    // per-instance state arrays are placed in front of it (an access below the allocation is an aperture violation).
+    if (lean) {
+      xs = q, q += M::NX * IPW;
+      xh = q, q += M::NX * IPW;
+      xT = q, q += 2 * M::NX * IPW;  // lean: two concurrent preamble sweeps
+      u0 = q, q += M::NU * IPW;      // lean: the control of the current tick for the plant step
+    }
     U = q, q += lean ? 0 : IPW * P.Lp;                 // lean: U aliases W (never dereferenced as U)
     Fh = q, q += plan == PLAN_FULL ? IPW * P.Lp : 0;  // otherwise Fh aliases W (the preamble moves the result to HBM)
     W = q, q += IPW * P.Lp;
@@ -144,10 +154,12 @@ struct WgLds {
     H = q, q += IPW * P.Hp;
     rho = q, q += IPW * k1;
     g = q, q += IPW * 3 * P.kmax;
-    xs = q, q += M::NX * IPW;
-    xh = q, q += M::NX * IPW;
-    xT = q, q += (lean ? 2 : 3) * M::NX * IPW;  // full plans: three concurrent preamble sweeps, lean: two
-    u0 = q, q += lean ? M::NU * IPW : 0;        // lean: the control of the current tick for the plant step
+    if (!lean) {
+      xs = q, q += M::NX * IPW;
+      xh = q, q += M::NX * IPW;
+      xT = q, q += 3 * M::NX * IPW;  // full plans: three concurrent preamble sweeps
+      u0 = q;
+    }
     int* z = reinterpret_cast<int*>(q);
     flag = z, reason = z + IPW, nax = z + 2 * IPW, ksolve = z + 3 * IPW;
   }
