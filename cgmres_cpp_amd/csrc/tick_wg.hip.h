@@ -1255,12 +1255,16 @@ struct WgCtx {
           default: break;
         }
       } else {
+        // streaming form with the next row requested before the current one is used (two rows in flight)
+        T vj[MAXM], vn[MAXM];
+        if (ks > 0) load_vec(vj, vrow(0));
         for (int j = 0; j < ks; ++j) {
-          T vj[MAXM];
-          load_vec(vj, vrow(j));
+          if (j + 1 < ks) load_vec(vn, vrow(j + 1));
           const T yj = rhoi[j];
 #pragma unroll
           for (int m = 0; m < MAXM; ++m) acc[m] += vj[m] * yj;
+#pragma unroll
+          for (int m = 0; m < MAXM; ++m) vj[m] = vn[m];
         }
       }
 #pragma unroll

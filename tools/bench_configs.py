@@ -81,8 +81,7 @@ def main():
             lo, hi = shard_bounds(Bg, world, rank)
             specs.append(dict(model=model, batch=hi - lo, dv=dv, k_max=kmax, tol=tol, dtype=dtype, device=local))
             shards.append((lo, hi))
-        streams = [torch.cuda.Stream(device=dev) for _ in members]
-        mc = MultipleController(specs, device=local, streams=[s.cuda_stream for s in streams])
+        mc = MultipleController(specs, device=local)  # (creates one stream per member, alternating priorities)
         tdt = torch.float64 if dtype == "f64" else torch.float32
         xs, us = [], []
         for m, (model, Bg, dv, kmax), (lo, hi) in zip(mc.members, members, shards):
