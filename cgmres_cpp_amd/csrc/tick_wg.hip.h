@@ -1137,11 +1137,17 @@ struct WgCtx {
         } else {
           // (register-starved lean kernels: v_k is streamed back from its row like the older ones instead of being
           // held in registers through the whole sweep; the row was written by this same thread)
+          // The next row is requested UNCONDITIONALLY (the last trip re-reads its own row): a guard would be a branch
+          // between a load and its use, and the compiler then waits with vmcnt(0) — i.e. also for the row it has just
+          // requested, and nothing overlaps.
           T vi[MAXM], vn[MAXM];
           const int kk = VK_IN_REGS ? k : k + 1;
           if (kk > 0) load_vec(vi, vrow(0));
           for (int i = 0; i < kk; ++i) {
-            if (i + 1 < kk) load_vec(vn, vrow(i + 1));
+            load_vec(vn, vrow(i + 1 < kk ? i + 1 : i));
+            // (keeps the requests of the next row TOGETHER and ahead of the arithmetic on the current one: under register
+            // pressure the scheduler otherwise sinks every load next to its use — one exposed round trip per element)
+            __builtin_amdgcn_sched_barrier(0);
             mgs_round(vi, i);
 #pragma unroll
             for (int m = 0; m < MAXM; ++m) vi[m] = vn[m];
@@ -1259,7 +1265,8 @@ struct WgCtx {
         T vj[MAXM], vn[MAXM];
         if (ks > 0) load_vec(vj, vrow(0));
         for (int j = 0; j < ks; ++j) {
-          if (j + 1 < ks) load_vec(vn, vrow(j + 1));
+          load_vec(vn, vrow(j + 1 < ks ? j + 1 : j));  // unconditional: see the Gram-Schmidt loop
+          __builtin_amdgcn_sched_barrier(0);
           const T yj = rhoi[j];
 #pragma unroll
           for (int m = 0; m < MAXM; ++m) acc[m] += vj[m] * yj;
