@@ -449,6 +449,7 @@ struct WgCtx {
       constexpr bool USE_ROT = CGM_AB_ROT != 0;
       T argp = T(0);
       int zmax = 0;
+      bool rot_ok = true;  // wave-uniform, per sweep: cleared by the first redo
       auto run = [&](auto mode_tag, int n) {
         constexpr int MODE = decltype(mode_tag)::value;
         auto stage = [&](int o, T u0) {
@@ -487,20 +488,24 @@ struct WgCtx {
             pu = U + s0 * NU;
             ua = pu[0];
           };
-          if constexpr (USE_ROT) {
+          bool fresh = !USE_ROT || !rot_ok;  // wave-uniform: run this chunk with a fresh evaluation per stage
+          if (USE_ROT && rot_ok) {
             // the chunk starts from a fresh value (the sweep's first one comes from quad_begin)
             if (s0 > 0) v = M::template quad_trig<false>(M::quad_arg(x, Q), Q, mc, &amax);
             argp = M::quad_arg(x, Q);
             run(std::integral_constant<int, 0>{}, n);
             if (__builtin_expect(__any(M::quad_rot_bad(zmax)), 0)) {  // an angle moved too far in one stage
-              rewind();
-              v = M::template quad_trig<false>(M::quad_arg(x, Q), Q, mc, &amax);
-              run(std::integral_constant<int, 1>{}, n);
-              if (n & 1) ua = pu[0];
+              fresh = true;
+              rot_ok = false;  // fast motion: the rest of this sweep evaluates afresh instead of paying for a rotation
+                               // pass AND its redo in every chunk
             }
             zmax = 0;
-          } else {
+          }
+          if (__builtin_expect(fresh, 0)) {
+            rewind();  // (a no-op in effect when no rotation pass ran)
+            v = M::template quad_trig<false>(M::quad_arg(x, Q), Q, mc, &amax);
             run(std::integral_constant<int, 1>{}, n);
+            if (n & 1) ua = pu[0];
           }
           // an argument outside the fast range of the trig kernel: redo this chunk with the library sin/cos
           if (__builtin_expect(__any(M::quad_arg_bad(amax)), 0)) {
