@@ -1,10 +1,12 @@
 // libcgmres_hip.so — extern "C" entry points of include/cgmres_hip.h.
 // Host side of the batched C/GMRES tick: a handle owns the HBM-resident controller state of `batch`
 // instances (the private members of the reference's Cgmres/Gmres objects, cgmres.hpp:195-202 /
-// gmres.hpp:120-124) behind one of two kernel mappings:
-//   variant 2 "wg"   (tick_wg.hip.h)   one workgroup per 16 (or 8) instances, LDS-staged sweeps, DPP row
-//                                      reductions — the default whenever the problem fits its LDS budget
-//   variant 1 "lane" (tick_lane.hip.h) one lane per instance, reference statement order, any size
+// gmres.hpp:120-124) behind one of three kernel mappings:
+//   variant 2 "wg"      (tick_wg.hip.h)   one workgroup per 16 (or 8) instances, LDS-staged sweeps, DPP row
+//                                         reductions — the default whenever the problem fits its LDS budget
+//   variant 3 "wg-lean" (tick_wg.hip.h)   the same on half the LDS: two workgroups per CU — the default when a batch
+//                                         needs more workgroups than the GPU has CUs
+//   variant 1 "lane"    (tick_lane.hip.h) one lane per instance, reference statement order, any size
 // There is no CPU implementation of the path in this library.
 #include <dlfcn.h>
 

@@ -1,4 +1,4 @@
-// Variant 2 ("wg"): one workgroup owns IPW controller instances for a whole control tick.
+// Variants 2 and 3 ("wg", "wg-lean"): one workgroup owns IPW controller instances for a whole control tick.
 //
 // Mapping (gfx950, wave64):
 //   * block = IPW*16 threads; thread (inst = tid/16, r = tid%16).  The 16 lanes of one DPP row own the
@@ -23,6 +23,12 @@
 //   * the serial phases run on ONE wave, which issues one instruction of any kind per ~4.4 cycles
 //     (tools/ubench_issue.hip): the stage loops are written for instruction count.
 //   * instances never exchange data: the only synchronisation is the workgroup barrier between phases.
+//   * variant 3 ("wg-lean", template parameter LEAN): the same kernel on half the LDS — U in the row lanes' registers (or
+//     re-read from its HBM row), F(U,x+hf,t+h) and ptau fetched from HBM/L2 a group of items ahead — so that two
+//     workgroups share a CU and their serial phases run side by side on different SIMDs (WgLds).
+//   * inside a chunk of stages the pendulum sweep advances its sin/cos values by rotation through the exact angle
+//     increment instead of re-evaluating them (PendulumDev::quad_stage_rot), with per-chunk fallbacks; in fixed-k mode
+//     (tol = 0) the Hessenberg column of an iteration is processed by an idle wave during the next sweep (gmres()).
 // Statement order inside each instance follows cgmres.hpp:78-175 / gmres.hpp:28-112; what differs from the
 // reference is the association order of sums (16 partial sums + butterfly; affine regrouping of the costate step).
 #pragma once
