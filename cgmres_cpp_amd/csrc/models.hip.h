@@ -351,6 +351,16 @@ struct PendulumDev {
   // operations of a wave complete in order); the table therefore has one pad stage after the last one (TAB_PAD).
   static constexpr bool HAS_QUAD_SWEEP = true;
   static constexpr int NSLOT = 6, TRIG_SLOT0 = 3, TAB_PAD = 1;
+  // x0 and x2 obey a recurrence of their own — x0' = x0 + dtau x2, x2' = x2 + dtau (-As x2 + Bs u0) (model.hpp:38,40) —
+  // that needs no trig value.  In the pipelined sweeps the sweep wave therefore writes them to the stage table at every
+  // OTHER stage only (an LDS store occupies the CU's LDS pipe for its 26 cycles whichever wave issues it), and the
+  // coefficient phase, which handles the two stages of a pair in one thread, re-derives the odd stage's values with
+  // the very same operations (bit-identical).
+  static __device__ __forceinline__ void x02_step(T& x0, T& x2, T u0, T dtau) {
+    const T f2 = fma_t(-As, x2, Bs * u0);
+    x0 = fma_t(dtau, x2, x0);
+    x2 = fma_t(dtau, f2, x2);
+  }
   static_assert(NBW <= NSLOT, "the junk redirection assumes the stage pitch is NSLOT");
   static constexpr int QSLOT_XA = 0, QSLOT_XB = 2, QLANE_TRUE_X = 2;  // write2 slots; a lane whose x[1] is +x1
   struct QuadLane {

@@ -410,7 +410,8 @@ struct WgCtx {
 
   // phase 1: state sweep, cgmres.hpp:132-140, on the lanes [lane0, lane0 + 64) of one wave; x(dv) -> xT[c*IPW + i].
   // PIPE: one lds_barrier() after every chunk (the caller's other waves run coeffs_chunked, which has the matching ones).
-  template <bool PERT, bool PIPE>
+  // ALT (quad sweep, pipelined only): x0 / x2 are stored at the first stage of every pair only (see M::x02_step)
+  template <bool PERT, bool PIPE, bool ALT = false>
   __device__ __forceinline__ void sweep_state(int lane0, const T* x0c, T dtau, T* tab, T* xT, bool only_active) {
     constexpr int NX = M::NX, NU = M::NU, NC = M::NC;
     constexpr int STEP = NSTG * IPW;
@@ -459,8 +460,10 @@ struct WgCtx {
       auto run = [&](auto mode_tag, int n) {
         constexpr int MODE = decltype(mode_tag)::value;
         auto stage = [&](int o, T u0) {
-          pa[o * STEP + M::QSLOT_XA * IPW] = x[0];
-          pa[o * STEP + M::QSLOT_XB * IPW] = x[2];
+          if (!ALT || o == 0) {  // (o is a literal at every call site)
+            pa[o * STEP + M::QSLOT_XA * IPW] = x[0];
+            pa[o * STEP + M::QSLOT_XB * IPW] = x[2];
+          }
           pb[o * STEP] = x[1];
           pv[o * STEP] = v;
           if constexpr (MODE == 0)
@@ -594,6 +597,11 @@ struct WgCtx {
   // barrier that releases the chunk): an item-by-item fetch exposes two dependent HBM/L2 round trips per item and
   // the coefficient waves then fall behind the sweep wave (measured: +20 % on every sweep).
   static constexpr bool HBM_OPERANDS = LEAN || MAXM > 10;  // kernels that carry the fh_hbm / lean code
+#ifndef CGM_AB_ALT_X02
+#define CGM_AB_ALT_X02 1
+#endif
+  // the pipelined quad sweep stores x0 / x2 every other stage; the coefficient phase works on stage pairs
+  static constexpr bool ALT_X02 = CGM_AB_ALT_X02 && M::HAS_QUAD_SWEEP && IPW * 16 >= 128;
   static constexpr int COEFF_GROUP = sizeof(T) == 8 ? 2 : 3;
   struct CoeffPre {
     T p[M::NP > 0 ? M::NP : 1], fh[M::NU];
@@ -613,14 +621,19 @@ struct WgCtx {
       for (int j = 0; j < M::NU; ++j) c.fh[j] = row[j];
     }
   }
+  // x02: x0 and x2 of this stage when the table does not hold them (second stage of a pair, ALT_X02)
   template <bool PERT, int MODE>
-  __device__ __forceinline__ void coeff_item(int s, int i, T dtau, const T* tab, T* out, const CoeffPre* pre = nullptr) {
+  __device__ __forceinline__ void coeff_item(int s, int i, T dtau, const T* tab, T* out, const CoeffPre* pre = nullptr,
+                                             const T* x02 = nullptr) {
     constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC, NBW = M::NBW;
     const T sc_phi = MODE == F_RHS ? P.one_m_zh : T(1.0);
     T x[NX], tr[NC > 0 ? NC : 1], u[NU], p[NP > 0 ? NP : 1], bw[NBW], phi[NU];
     const T* Rs = tab + (s * NSTG) * IPW + i;
 #pragma unroll
     for (int c = 0; c < NX; ++c) x[c] = Rs[c * IPW];
+    if constexpr (ALT_X02) {
+      if (x02) x[0] = x02[0], x[2] = x02[1];
+    }
 #pragma unroll
     for (int c = 0; c < NC; ++c) tr[c] = Rs[(M::TRIG_SLOT0 + c) * IPW];
 #pragma unroll
@@ -677,6 +690,36 @@ struct WgCtx {
       if (q < n_items && item_on(i, only_active)) coeff_item<PERT, MODE>(s0 + q / IPW, i, dtau, tab, out, &pre[g]);
     }
   }
+  // the same for items = (stage pair, instance) of the stages [s0, s_end) of the LDS table (ALT_X02): the second stage
+  // of a pair takes x0 / x2 from M::x02_step instead of the table
+  template <bool PERT, int MODE, class Between>
+  __device__ __forceinline__ void coeff_group_pairs(int q0, int stride, int s0, int s_end, T dtau, T* out,
+                                                    bool only_active, Between&& between) {
+    const int n_items = ((s_end - s0 + 1) >> 1) * IPW;
+    CoeffPre pre[COEFF_GROUP][2];
+#pragma unroll
+    for (int g = 0; g < COEFF_GROUP; ++g) {
+      const int q = q0 + g * stride, i = q & (IPW - 1), s = s0 + 2 * (q / IPW);
+      if (q < n_items && item_on(i, only_active)) {
+        coeff_prefetch<MODE>(pre[g][0], s, i);
+        if (s + 1 < s_end) coeff_prefetch<MODE>(pre[g][1], s + 1, i);
+      }
+    }
+    between();
+#pragma unroll
+    for (int g = 0; g < COEFF_GROUP; ++g) {
+      const int q = q0 + g * stride, i = q & (IPW - 1), s = s0 + 2 * (q / IPW);
+      if (q < n_items && item_on(i, only_active)) {
+        T x02[2] = {S.R[(s * NSTG + M::QSLOT_XA) * IPW + i], S.R[(s * NSTG + M::QSLOT_XB) * IPW + i]};
+        const T u0 = (PERT || LEAN ? S.W : S.U)[i * P.Lp + s * M::NU];
+        coeff_item<PERT, MODE>(s, i, dtau, S.R, out, &pre[g][0]);
+        if (s + 1 < s_end) {
+          M::x02_step(x02[0], x02[1], u0, dtau);
+          coeff_item<PERT, MODE>(s + 1, i, dtau, S.R, out, &pre[g][1], x02);
+        }
+      }
+    }
+  }
   template <bool PERT, int MODE>
   __device__ __forceinline__ void sweep_coeffs(T dtau, const T* tab, T* out, bool only_active) {
     if constexpr (HBM_OPERANDS) {
@@ -697,12 +740,29 @@ struct WgCtx {
     const int dv = P.dv, CH = chunk_len(), lt = tid - 64;
     for (int s0 = 0; s0 < dv; s0 += CH) {
       const int n = dv - s0 < CH ? dv - s0 : CH;
-      if constexpr (HBM_OPERANDS) {
+      if constexpr (HBM_OPERANDS && ALT_X02) {
+        coeff_group_pairs<PERT, MODE>(lt, NL, s0, s0 + n, dtau, out, only_active, [&] { lds_barrier(); });
+        for (int q0 = lt + NL * COEFF_GROUP; q0 < ((n + 1) >> 1) * IPW; q0 += NL * COEFF_GROUP)
+          coeff_group_pairs<PERT, MODE>(q0, NL, s0, s0 + n, dtau, out, only_active, [] {});
+      } else if constexpr (HBM_OPERANDS) {
         // the first group's HBM operands are requested BEFORE the barrier, i.e. while the sweep wave still works on
         // this chunk (every thread reaches the barrier exactly once per chunk, with or without items)
         coeff_group<PERT, MODE>(lt, NL, n * IPW, s0, dtau, S.R, out, only_active, [&] { lds_barrier(); });
         for (int q0 = lt + NL * COEFF_GROUP; q0 < n * IPW; q0 += NL * COEFF_GROUP)
           coeff_group<PERT, MODE>(q0, NL, n * IPW, s0, dtau, S.R, out, only_active, [] {});
+      } else if constexpr (ALT_X02) {
+        lds_barrier();
+        for (int q = lt; q < ((n + 1) >> 1) * IPW; q += NL) {  // items = (stage pair, instance)
+          const int i = q & (IPW - 1), s = s0 + 2 * (q / IPW);
+          if (!item_on(i, only_active)) continue;
+          T x02[2] = {S.R[(s * NSTG + M::QSLOT_XA) * IPW + i], S.R[(s * NSTG + M::QSLOT_XB) * IPW + i]};
+          const T u0 = (PERT || LEAN ? S.W : S.U)[i * P.Lp + s * M::NU];
+          coeff_item<PERT, MODE>(s, i, dtau, S.R, out);
+          if (s + 1 < s0 + n) {
+            M::x02_step(x02[0], x02[1], u0, dtau);
+            coeff_item<PERT, MODE>(s + 1, i, dtau, S.R, out, nullptr, x02);
+          }
+        }
       } else {
         lds_barrier();
         for (int q = lt; q < n * IPW; q += NL) {
@@ -803,7 +863,7 @@ struct WgCtx {
                                          Idle&& idle_work) {
     if constexpr (IPW * 16 >= 128) {
       if (tid < 64) {
-        sweep_state<PERT, true>(0, x0c, dtau, S.R, S.xT, only_active);
+        sweep_state<PERT, true, ALT_X02>(0, x0c, dtau, S.R, S.xT, only_active);
         after_sweep();
       } else {
         idle_work();
@@ -823,7 +883,7 @@ struct WgCtx {
   __device__ __forceinline__ void f_eval(const T* x0c, T dtau, T* out, bool only_active) {
     if constexpr (IPW * 16 >= 128) {
       if (tid < 64)
-        sweep_state<PERT, true>(0, x0c, dtau, S.R, S.xT, only_active);
+        sweep_state<PERT, true, ALT_X02>(0, x0c, dtau, S.R, S.xT, only_active);
       else
         coeffs_chunked<PERT, MODE>(dtau, out, only_active);
       CGM_STAMP(*this, 4);
