@@ -448,8 +448,8 @@ struct PendulumDev {
   // d = arg(s+1) - arg(s) (exact: both are within a factor two of each other) instead of a fresh evaluation:
   //   v' = v + (v (cos d - 1) + v_partner (+-sin d)),   v_partner = the other kernel of this lane's angle (quad swap)
   // 17 instructions instead of 27 (no argument reduction, no quadrant logic, two short Taylor polynomials).  Each step
-  // adds ~2 ulp of rounding; the sweep restarts from a fresh evaluation at every chunk of stages (<= 2*ceil(dv/8)), so
-  // the accumulated error stays below ~30 ulp worst case, ~6 ulp typical — 4 orders of magnitude inside the parity
+  // adds ~2 ulp of rounding; the sweep restarts from a fresh evaluation at every chunk of stages (~25, WgCtx::chunk_len),
+  // so the accumulated error stays below ~50 ulp worst case, ~8 ulp typical — 4 orders of magnitude inside the parity
   // tolerance on u.  *zmax accumulates max d^2 (integer view): a chunk whose increments leave |d| <= sqrt(rot_zmax)
   // is redone with fresh evaluations per stage (quad_stage<false>).
   template <class MC>

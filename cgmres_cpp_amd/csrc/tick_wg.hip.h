@@ -404,9 +404,13 @@ struct WgCtx {
   }
   // Phases 1 and 2 are pipelined in chunks of stages (f_eval): the sweep wave publishes a chunk of the stage table
   // and goes on with the next one while the other waves turn the published chunk into costate coefficients.
-  // Four chunks measured best at dv = 50 (14+14+14+8): a barrier costs the sweep wave ~300 cycles, and only the
-  // processing of the last chunk stays on the critical path.
-  __device__ __forceinline__ int chunk_len() const { return 2 * ((P.dv + 7) / 8); }  // even: stages go in pairs
+  // Chunks of ~25 stages measured best (round 2, after the coefficient phase moved to stage pairs: 2 chunks at dv = 50 —
+  // 1: -5 %, 3: -1.2 %, 4: -2.5 %, 5: -4 % — and 4 at dv = 100; round 1 had 4 at dv = 50): a barrier costs the sweep
+  // wave ~300 cycles, and only the processing of the last chunk stays on the critical path.
+  __device__ __forceinline__ int chunk_len() const {  // even: stages go in pairs
+    const int chunks = P.dv <= 64 ? 2 : 4;
+    return 2 * ((P.dv + 2 * chunks - 1) / (2 * chunks));
+  }
 
   // phase 1: state sweep, cgmres.hpp:132-140, on the lanes [lane0, lane0 + 64) of one wave; x(dv) -> xT[c*IPW + i].
   // PIPE: one lds_barrier() after every chunk (the caller's other waves run coeffs_chunked, which has the matching ones).
