@@ -464,7 +464,7 @@ struct WgCtx {
       auto run = [&](auto mode_tag, int n) {
         constexpr int MODE = decltype(mode_tag)::value;
         auto stage = [&](int o, T u0) {
-          if (!ALT || o == 0) {  // (o is a literal at every call site)
+          if (!ALT || (o & 1) == 0) {  // (o is a literal at every call site)
             pa[o * STEP + M::QSLOT_XA * IPW] = x[0];
             pa[o * STEP + M::QSLOT_XB * IPW] = x[2];
           }
@@ -476,6 +476,22 @@ struct WgCtx {
             M::template quad_stage<MODE == 2>(x, v, u0, dtau, dtau1, Q, mc, &amax);
         };
         int k = 0;
+#ifndef CGM_AB_UNROLL4
+#define CGM_AB_UNROLL4 1
+#endif
+        if constexpr (CGM_AB_UNROLL4 && MODE == 0) {  // rotation mode: four stages per trip (a taken branch costs ~30 cycles)
+          for (; k + 4 <= n; k += 4) {
+            const T ub = pu[NU];
+            stage(0, ua);
+            const T uc = pu[2 * NU];
+            stage(1, ub);
+            const T ud = pu[3 * NU];
+            stage(2, uc);
+            ua = pu[4 * NU];
+            stage(3, ud);
+            pa += 4 * STEP, pb += 4 * STEP, pv += 4 * STEP, pu += 4 * NU;
+          }
+        }
         for (; k + 2 <= n; k += 2) {
           const T ub = pu[NU];
           stage(0, ua);
