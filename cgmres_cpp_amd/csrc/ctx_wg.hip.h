@@ -40,14 +40,20 @@ struct CtxWg final : cgmres_hip_ctx {
   // (IPW, MAXM) instantiations: 16 or 8 instances per workgroup, vectors up to 160 or 320 elements; the lean LDS plan
   // (two workgroups per CU) exists for 16 instances per workgroup
   template <int IPW, int MAXM>
-  void pick(bool lean) {
+  void pick(bool lean, bool par) {
     k_tick = tick_wg_kernel<M, T, IPW, MAXM>;
     if constexpr (IPW == 16) {
       if (lean) k_tick = tick_wg_kernel<M, T, IPW, MAXM, true>;
+      if constexpr (kParCostate<MAXM>) {
+        if (par && !lean) k_tick = tick_wg_kernel<M, T, IPW, MAXM, false, true>;
+      }
     }
     k_hook = hook_wg_kernel<M, T, IPW, MAXM>;
     ipw = IPW, maxm = MAXM;
   }
+  // kernels with the chunk-parallel costate sweep (WgCtx::sweep_costate_par) exist for the short-vector instantiations
+  template <int MAXM>
+  static constexpr bool kParCostate = M::COSTATE_HOM && MAXM == 10 && M::NX * 16 <= 64;
   static int pitch_H(int k_max) { return ((k_max * (k_max + 3)) / 2) | 1; }
   // lean plan: 16 instances per workgroup in at most half a CU's LDS; the white-box hooks keep running on the full
   // (or fh_hbm) plan of the same sizes, so that one must fit as well
@@ -125,10 +131,18 @@ struct CtxWg final : cgmres_hip_ctx {
     cfg.variant = lean ? 3 : 2;
     const int fh_hbm_hook = lean ? [&] { int i, f = 0; size_t bb; supported(cfg, &i, &bb, &f); return f; }() : fh_hbm;
     const bool big = L > 160;
-    if (want == 16 && !big) pick<16, 10>(lean);
-    if (want == 16 && big) pick<16, 20>(lean);
-    if (want == 8 && !big) pick<8, 10>(false);
-    if (want == 8 && big) pick<8, 20>(false);
+    // chunk-parallel costate sweep (WgCtx::sweep_costate_par): its own kernel instantiation on the full plan, taken when
+    // its scratch fits as well (the white-box hooks keep the serial sweep)
+    bool par = false;
+    if (kParCostate<10> && want == 16 && !big && !lean && cfg.dv >= 4) {
+      const char* e = getenv("CGMRES_HIP_COSTATE");  // A/B switch for measurements: "serial"
+      const size_t extra = WgLds<M, T, 16>::scan_count(cfg.dv) * sizeof(T) + 16;
+      if (lds_bytes + extra <= kLdsLimit && !(e && !strcmp(e, "serial"))) par = true, lds_bytes += extra;
+    }
+    if (want == 16 && !big) pick<16, 10>(lean, par);
+    if (want == 16 && big) pick<16, 20>(lean, false);
+    if (want == 8 && !big) pick<8, 10>(false, false);
+    if (want == 8 && big) pick<8, 20>(false, false);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 int(lds_bytes)));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hook), hipFuncAttributeMaxDynamicSharedMemorySize,

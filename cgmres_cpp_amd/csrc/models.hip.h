@@ -303,7 +303,11 @@ struct PendulumDev {
   // --- affine-in-costate split of the backward stage (see the interface note at the top of the file) ---
   // dHdx = qx(x,p) + J(x,u)^T l and dHdu = phi(u) + B(x)^T l (model.hpp:51-62 regrouped); q2 = q3 = 0 here,
   // so the l-free parts of rows 2,3 vanish and are not stored.
-  static constexpr int NBW = 6, NUL = 1;
+  // Coefficient order: the NBW_LIN entries that multiply l first, the l-free (bias) entries last — the recurrence is
+  // affine in l, so a chunk of stages can also be run from a unit vector WITHOUT the bias (costate_step<true>: one
+  // column of the chunk's transfer matrix; WgCtx::sweep_costate_par) and such a lane fetches the first NBW_LIN only.
+  static constexpr int NBW = 6, NUL = 1, NBW_LIN = 4;
+  static constexpr bool COSTATE_HOM = true;
   static_assert(q2 == T(0.0) && q3 == T(0.0), "pendulum stage coefficients assume q2 = q3 = 0");
   static __device__ __forceinline__ void stage_coeffs(T* bw, T* phi, const T* x, const T* u, const T* p,
                                                       const T* trig, T dtau) {
@@ -311,23 +315,24 @@ struct PendulumDev {
     const T S0 = A32 * x[2] * x[2] * cd + A32b * sd * u[0] - A32a * sd * x[2];                  // l3 coeff, row 0
     const T S1 = -A32 * x[2] * x[2] * cd + A52 * c1 - A32b * sd * u[0] + A32a * sd * x[2];      // l3 coeff, row 1
     const T S2 = T(2.0) * A32 * x[2] * sd + A32a * cd + C22;                                    // l3 coeff, row 2
-    bw[0] = dtau * ((x[0] - p[0]) * q0);
-    bw[1] = dtau * S0;
-    bw[2] = dtau * ((x[1] - p[1]) * q1);
-    bw[3] = dtau * S1;
-    bw[4] = dtau * S2;
-    bw[5] = -A32b * cd;  // l3 coeff of dHdu[0]
+    bw[0] = dtau * S0;
+    bw[1] = dtau * S1;
+    bw[2] = dtau * S2;
+    bw[3] = -A32b * cd;  // l3 coeff of dHdu[0]
+    bw[4] = dtau * ((x[0] - p[0]) * q0);
+    bw[5] = dtau * ((x[1] - p[1]) * q1);
     phi[0] = (r0 * u[0]) + (u[2] * (T(2.0) * u[0] - T(2.0) * uc));
     phi[1] = T(-0.5) * r1 + (T(2.0) * u[2] * u[1]);
     phi[2] = (u[0] - uc) * (u[0] - uc) + u[1] * u[1] - ur * ur;
   }
   // l <- l + dtau*dHdx(l) and dF = B^T l_old, from the stored coefficients
+  template <bool HOM = false>
   static __device__ __forceinline__ void costate_step(T* l, T* dF, const T* bw, T dtau) {
-    dF[0] = l[2] * Bs + bw[5] * l[3];
-    const T n0 = (l[0] + bw[0]) + bw[1] * l[3];
-    const T n1 = (l[1] + bw[2]) + bw[3] * l[3];
+    dF[0] = l[2] * Bs + bw[3] * l[3];
+    const T n0 = HOM ? fma_t(bw[0], l[3], l[0]) : (l[0] + bw[4]) + bw[0] * l[3];
+    const T n1 = HOM ? fma_t(bw[1], l[3], l[1]) : (l[1] + bw[5]) + bw[1] * l[3];
     // (1 - dtau*As) and (1 - dtau*C22) are loop invariants of the sweep: 5 instructions for the two rows instead of 7
-    const T n2 = __builtin_fma(bw[4], l[3], __builtin_fma(dtau, l[0], (T(1.0) - dtau * As) * l[2]));
+    const T n2 = __builtin_fma(bw[2], l[3], __builtin_fma(dtau, l[0], (T(1.0) - dtau * As) * l[2]));
     const T n3 = __builtin_fma(dtau, l[1], (T(1.0) - dtau * C22) * l[3]);
     l[0] = n0, l[1] = n1, l[2] = n2, l[3] = n3;
   }
@@ -541,7 +546,8 @@ struct MsdDev {
   static constexpr bool HAS_QUAD_SWEEP = false;  // no transcendental in the state equation: nothing to spread
   static constexpr int NSLOT = NX + NC, TRIG_SLOT0 = NX, TAB_PAD = 0;
   // affine-in-costate split (model.hpp:50-64 regrouped): the Jacobian is constant, only qx depends on the stage
-  static constexpr int NBW = 4, NUL = 2;
+  static constexpr int NBW = 4, NUL = 2, NBW_LIN = 0;  // (all four are bias entries, see PendulumDev::NBW_LIN)
+  static constexpr bool COSTATE_HOM = true;
   static __device__ __forceinline__ void stage_coeffs(T* bw, T* phi, const T* x, const T* u, const T* p, const T*,
                                                       T dtau) {
     bw[0] = dtau * (-(p[0] - x[0]) * q0);
@@ -555,13 +561,14 @@ struct MsdDev {
     phi[4] = (u[0] - uc) * (u[0] - uc) + u[2] * u[2] - ur * ur;
     phi[5] = (u[1] - uc) * (u[1] - uc) + u[3] * u[3] - ur * ur;
   }
+  template <bool HOM = false>
   static __device__ __forceinline__ void costate_step(T* l, T* dF, const T* bw, T dtau) {
     dF[0] = l[2] / m1;
     dF[1] = l[3] / m2;
-    const T n0 = (l[0] + bw[0]) + dtau * (-(k1 + k2) / m1 * l[2] + k2 / m2 * l[3]);
-    const T n1 = (l[1] + bw[1]) + dtau * (k2 / m1 * l[2] - k2 / m2 * l[3]);
-    const T n2 = (l[2] + bw[2]) + dtau * (l[0] - (d1 + d2) / m1 * l[2] + d2 / m2 * l[3]);
-    const T n3 = (l[3] + bw[3]) + dtau * (l[1] + d2 / m1 * l[2] - d2 / m2 * l[3]);
+    const T n0 = (HOM ? l[0] : l[0] + bw[0]) + dtau * (-(k1 + k2) / m1 * l[2] + k2 / m2 * l[3]);
+    const T n1 = (HOM ? l[1] : l[1] + bw[1]) + dtau * (k2 / m1 * l[2] - k2 / m2 * l[3]);
+    const T n2 = (HOM ? l[2] : l[2] + bw[2]) + dtau * (l[0] - (d1 + d2) / m1 * l[2] + d2 / m2 * l[3]);
+    const T n3 = (HOM ? l[3] : l[3] + bw[3]) + dtau * (l[1] + d2 / m1 * l[2] - d2 / m2 * l[3]);
     l[0] = n0, l[1] = n1, l[2] = n2, l[3] = n3;
   }
   static __device__ __forceinline__ void ddHduu(T* m, const T*, const T* u, const T*, const T*) {  // :66-108
@@ -617,21 +624,23 @@ struct SemiactiveDev {
   static constexpr bool HAS_QUAD_SWEEP = false;
   static constexpr int NSLOT = NX + NC, TRIG_SLOT0 = NX, TAB_PAD = 0;
   // affine-in-costate split (model.hpp:46-55 regrouped)
-  static constexpr int NBW = 4, NUL = 1;
+  static constexpr int NBW = 4, NUL = 1, NBW_LIN = 2;  // (see PendulumDev::NBW_LIN)
+  static constexpr bool COSTATE_HOM = true;
   static __device__ __forceinline__ void stage_coeffs(T* bw, T* phi, const T* x, const T* u, const T*, const T*,
                                                       T dtau) {
-    bw[0] = dtau * (x[0] * q0);
-    bw[1] = dtau * (x[1] * q1);
-    bw[2] = dtau * (b * u[0]);  // l1 coeff, row 1
-    bw[3] = b * x[1];           // l1 coeff of dHdu[0]
+    bw[0] = dtau * (b * u[0]);  // l1 coeff, row 1
+    bw[1] = b * x[1];           // l1 coeff of dHdu[0]
+    bw[2] = dtau * (x[0] * q0);
+    bw[3] = dtau * (x[1] * q1);
     phi[0] = r0 * u[0] + 2 * u[2] * (u[0] - uc);
     phi[1] = -r1 + 2 * u[1] * u[2];
     phi[2] = (u[0] - uc) * (u[0] - uc) + u[1] * u[1] - ur * ur;
   }
+  template <bool HOM = false>
   static __device__ __forceinline__ void costate_step(T* l, T* dF, const T* bw, T dtau) {
-    dF[0] = bw[3] * l[1];
-    const T n0 = (l[0] + bw[0]) + dtau * (a * l[1]);
-    const T n1 = (l[1] + bw[1]) + (dtau * l[0] + bw[2] * l[1]);
+    dF[0] = bw[1] * l[1];
+    const T n0 = (HOM ? l[0] : l[0] + bw[2]) + dtau * (a * l[1]);
+    const T n1 = (HOM ? l[1] : l[1] + bw[3]) + (dtau * l[0] + bw[0] * l[1]);
     l[0] = n0, l[1] = n1;
   }
   static __device__ __forceinline__ void ddHduu(T* m, const T*, const T* u, const T*, const T*) {  // :57-69

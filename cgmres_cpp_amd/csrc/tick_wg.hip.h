@@ -88,18 +88,34 @@ struct WgParams {
 // (kept out of WgParams on purpose: any use of the kernel-argument struct through a pointer made hipcc spill the whole
 // struct to scratch and distorted the very thing being measured).
 __device__ long long g_cgm_stamps[64];
+// The per-phase totals are accumulated in LDS (static, outside the dynamic carve-up) and added to the global buffer
+// once at the end of the kernel: a global atomic per stamp queues behind the basis-row loads in flight and made the
+// stamps after them look ~1.5 k cycles long.
+__device__ __forceinline__ long long* cgm_stamp_lds() {
+  __shared__ long long acc[66];  // [0..31] cycles, [32..63] visits, [64] last stamp
+  return acc;
+}
 __device__ __forceinline__ void cgm_stamp(int id) {
-  __shared__ long long t_last;  // LDS, not global: a global read would make every stamp drain vmcnt(0)
   if (threadIdx.x == 0 && blockIdx.x == 0) {
+    long long* acc = cgm_stamp_lds();
     const long long now = (long long)__builtin_amdgcn_s_memtime();
     if (id >= 0) {
-      __hip_atomic_fetch_add(&g_cgm_stamps[id], now - t_last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(&g_cgm_stamps[32 + id], 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      acc[id] += now - acc[64];
+      acc[32 + id] += 1;
     } else {
+      for (int i = 0; i < 64; ++i) acc[i] = 0;
       g_cgm_stamps[30] = (long long)__builtin_amdgcn_s_memrealtime();
       g_cgm_stamps[31] = now;
     }
-    t_last = now;
+    acc[64] = now;
+  }
+}
+__device__ __forceinline__ void cgm_stamp_flush() {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    long long* acc = cgm_stamp_lds();
+    for (int i = 0; i < 28; ++i) g_cgm_stamps[i] += acc[i], g_cgm_stamps[32 + i] += acc[32 + i];
+    g_cgm_stamps[28] += (long long)__builtin_amdgcn_s_memrealtime() - g_cgm_stamps[30];
+    g_cgm_stamps[29] += (long long)__builtin_amdgcn_s_memtime() - g_cgm_stamps[31];
   }
 }
 #define CGM_STAMP(ctx, id) cgm_stamp(id)
@@ -126,6 +142,7 @@ struct WgLds {
   static constexpr int NSTG = M::NSLOT > M::NBW ? M::NSLOT : M::NBW;
   static constexpr int TAB_PAD = M::TAB_PAD;
   T *U, *Fh, *W, *R, *p, *H, *rho, *g, *xs, *xh, *xT, *u0;  // xT: terminal states of the state sweeps in flight
+  T* scan;  // scratch of the chunk-parallel costate sweep (WgCtx::sweep_costate_par), full plans only
   int *flag, *reason, *nax, *ksolve;
   static __host__ __device__ size_t tab_count(int dv) { return size_t(dv + TAB_PAD) * NSTG * IPW; }
   static __host__ __device__ size_t count_T(int dv, int kmax, int Lp, int Pp, int Hp, int plan = PLAN_FULL) {
@@ -135,8 +152,16 @@ struct WgLds {
            size_t(IPW) * k1 + size_t(IPW) * 3 * kmax + size_t(plan == PLAN_LEAN ? 4 : 5) * M::NX * IPW +
            (plan == PLAN_LEAN ? size_t(M::NU) * IPW : 0);
   }
-  static __host__ __device__ size_t bytes(int dv, int kmax, int Lp, int Pp, int Hp, int plan = PLAN_FULL) {
-    return count_T(dv, kmax, Lp, Pp, Hp, plan) * sizeof(T) + 4 * IPW * sizeof(int) + 16;
+  // chunk-parallel costate sweep (WgCtx::sweep_costate_par): dF of the homogeneous lanes for the 3*(dv/4) stages of
+  // chunks 1..3, then four boundary records per instance (k = 0..3): [NX*NX transfer matrix, row-major][NX vector]
+  // [pad], read with 16-byte loads — SCAN_REC doubles apart so that the 16 instances of a read fall into distinct banks
+  // (22 scalars = 44 banks for NX = 4: i*44 mod 64 are 16 distinct multiples of 4)
+  static constexpr int SCAN_REC = M::NX * M::NX + M::NX + 2;
+  static __host__ __device__ size_t scan_count(int dv) {
+    return size_t(3 * (dv >> 2)) * M::NUL * M::NX * IPW + size_t(4) * IPW * SCAN_REC;
+  }
+  static __host__ __device__ size_t bytes(int dv, int kmax, int Lp, int Pp, int Hp, int plan = PLAN_FULL, bool par = false) {
+    return count_T(dv, kmax, Lp, Pp, Hp, plan) * sizeof(T) + 4 * IPW * sizeof(int) + 16 + (par ? scan_count(dv) * sizeof(T) + 16 : 0);
   }
   __device__ __forceinline__ WgLds(unsigned char* base, const WgParams<T>& P, int plan) {
     T* q = reinterpret_cast<T*>(base);
@@ -168,11 +193,15 @@ struct WgLds {
     }
     int* z = reinterpret_cast<int*>(q);
     flag = z, reason = z + IPW, nax = z + 2 * IPW, ksolve = z + 3 * IPW;
+    // 16-byte aligned (records are read in pairs) — as an OFFSET from the base: a pointer-integer-pointer round trip
+    // loses the LDS address space and every access through `scan` becomes a flat load behind s_waitcnt vmcnt(0)
+    const unsigned scan_off = unsigned(reinterpret_cast<unsigned char*>(z + 4 * IPW) - base);
+    scan = reinterpret_cast<T*>(base + ((scan_off + 15u) & ~15u));
   }
 };
 
 // Per-thread view of one workgroup's job.
-template <class M, class T, int IPW, int MAXM, bool LEAN = false>
+template <class M, class T, int IPW, int MAXM, bool LEAN = false, bool PAR = false>
 struct WgCtx {
   using Lds = WgLds<M, T, IPW>;
   static constexpr int NSTG = Lds::NSTG;
@@ -794,23 +823,46 @@ struct WgCtx {
     }
   }
 
-  // phase 3: costate sweep (cgmres.hpp:145-153) + the costate part of dH/du (:156-161), lanes 0..IPW-1 of wave 0
+  // phase 3: costate sweep (cgmres.hpp:145-153) + the costate part of dH/du (:156-161).  COLLECTIVE (every thread
+  // calls it); the caller adds the barrier that publishes `out`.
   template <int MODE>
   __device__ __forceinline__ void sweep_costate(T dtau, const T* xT, T* out, bool only_active) {
-    constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NBW = M::NBW, NUL = M::NUL;
-    const int dv = P.dv;
-    if (!(sweep_lane && (!only_active || S.flag[tid]))) return;
-    const int i = tid;
-    const T sc = MODE == F_PLAIN ? T(1.0) : (MODE == F_RHS ? P.one_m_zh * P.inv_h : P.inv_h);
-    T l[NX], xs[NX], p[NP > 0 ? NP : 1];
+    if constexpr (PAR_COSTATE) {
+      sweep_costate_par<MODE>(dtau, xT, out, only_active);
+    } else {
+      if (!(sweep_lane && (!only_active || S.flag[tid]))) return;
+      T l[M::NX];
+      costate_run<MODE, false>(l, tid, P.dv - 1, P.dv, dtau, S.R + 2 * tid, out + tid * P.Lp,
+                               [&](T* l0) { costate_terminal(l0, xT, tid); });
+    }
+  }
+  __device__ __forceinline__ void costate_terminal(T* l, const T* xT, int i) const {
+    T xs[M::NX], p[M::NP > 0 ? M::NP : 1];
 #pragma unroll
-    for (int c = 0; c < NX; ++c) xs[c] = xT[c * IPW + i];
+    for (int c = 0; c < M::NX; ++c) xs[c] = xT[c * IPW + i];
 #pragma unroll
-    for (int j = 0; j < NP; ++j) p[j] = get_p(i, dv * NP + j);
+    for (int j = 0; j < M::NP; ++j) p[j] = get_p(i, P.dv * M::NP + j);
     M::dPhidx(l, xs, p);
-    // One wave issues one instruction per ~4.4 cycles whatever it is (tools/ubench_issue.hip), so the loop is written
-    // for instruction count: moving pointers with immediate offsets, no branch inside a trip, unconditional
-    // look-ahead fetches.
+  }
+  // `count` (workgroup-uniform) stages hi, hi-1, ... of the recurrence on this lane, from l.
+  //   HOM = false: the affine stage; coefficients from `coef` (this instance's pairs of stage 0), the costate part of
+  //                dH/du is added to the row `orow`: orow[s*NU + j] += sc*dF[j]
+  //   HOM = true:  the bias-free stage on the first NBW_LIN coefficients; dF itself goes to orow[(s*NUL + j)*HL]
+  // One wave issues one instruction per ~4.4 cycles whatever it is (tools/ubench_issue.hip), so the loop is written
+  // for instruction count: moving pointers with immediate offsets, no branch inside a trip, unconditional look-ahead
+  // fetches.
+  //   After the `count` common stages, lanes with `more` set go on for `extra` (workgroup-uniform, 0..3) stages; the
+  //   first two of those use operands the look-ahead has fetched anyway.  `init` fills l; it is called after the first
+  //   operand requests have been issued so that its own LDS reads share their round trip.
+  template <int MODE, bool HOM, class Init>
+  __device__ __forceinline__ void costate_run(T* l, int i, int hi, int count, T dtau, const T* coef, T* orow, Init&& init,
+                                              int extra = 0, bool more = false) {
+    constexpr int NU = M::NU, NBW = M::NBW, NUL = M::NUL;
+    constexpr int NLOAD = HOM ? M::NBW_LIN : NBW;  // coefficients fetched per stage
+    constexpr int OJ = HOM ? HL : 1;               // distance between the NUL outputs of a stage
+    constexpr int opitch = HOM ? NUL * HL : NU;    // and between stages
+    static_assert(NLOAD % 2 == 0, "coefficients are fetched in pairs");
+    const T sc = MODE == F_PLAIN ? T(1.0) : (MODE == F_RHS ? P.one_m_zh * P.inv_h : P.inv_h);
     constexpr int STEP = NSTG * IPW;
     struct Ops {
       T bw[NBW], o[NUL];
@@ -818,18 +870,20 @@ struct WgCtx {
     auto fetch = [&](Ops& a, const T* pr, const T* po) {
       const Pair* pp = reinterpret_cast<const Pair*>(pr);
 #pragma unroll
-      for (int c = 0; c < NBW; c += 2) {
+      for (int c = 0; c < NLOAD; c += 2) {
         const Pair t = pp[(c / 2) * IPW];
         a.bw[c] = t.a, a.bw[c + 1] = t.b;
       }
+      if constexpr (!HOM) {
 #pragma unroll
-      for (int j = 0; j < NUL; ++j) a.o[j] = po[j];
+        for (int j = 0; j < NUL; ++j) a.o[j] = po[j * OJ];
+      }
     };
     auto stage = [&](const Ops& a, T* po) {
       T dF[NUL];
-      M::costate_step(l, dF, a.bw, dtau);
+      M::template costate_step<HOM>(l, dF, a.bw, dtau);
 #pragma unroll
-      for (int j = 0; j < NUL; ++j) po[j] = a.o[j] + dF[j] * sc;
+      for (int j = 0; j < NUL; ++j) po[j * OJ] = HOM ? dF[j] : a.o[j] + dF[j] * sc;
     };
     // Three register sets, three stages per trip: the operands of stage t-2 are requested while stage t computes
     // (two LDS latencies of slack).  q/o sit on stage s-4 of the trip that starts with stage s: every access is
@@ -839,13 +893,14 @@ struct WgCtx {
 #ifdef CGM_DEBUG_LDS
     auto chk = [&](const void* ptr, int what) {
       const long off = static_cast<const char*>(ptr) - reinterpret_cast<const char*>(S.U);
-      if (off < 0 || off + 16 > long(P.lds_bytes)) printf("LDS OOB what=%d off=%ld tid=%d dv=%d\n", what, off, tid, dv);
+      if (off < 0 || off + 16 > long(P.lds_bytes)) printf("LDS OOB what=%d off=%ld tid=%d dv=%d\n", what, off, tid, P.dv);
     };
 #else
     auto chk = [&](const void*, int) {};
 #endif
     auto fetch3 = [&](Ops& a, const T* pr3, const T* po3) {
-      chk(pr3, 1), chk(pr3 + (NBW / 2 - 1) * 2 * IPW, 2), chk(po3, 3);
+      if (NLOAD) chk(pr3, 1), chk(pr3 + (NLOAD / 2 - 1) * 2 * IPW, 2);
+      if (!HOM) chk(po3, 3);
       fetch(a, pr3, po3);
     };
     auto stage3 = [&](const Ops& a, T* po3) {
@@ -853,22 +908,159 @@ struct WgCtx {
       stage(a, po3);
     };
     Ops A, B, C;
-    int s = dv - 1;
-    const T* q = S.R + 2 * i + (dv - 5) * STEP;  // pair-interleaved coefficients, see coeff_item
-    T* o = out + i * P.Lp + (dv - 5) * NU;
-    fetch3(A, q + 4 * STEP, o + 4 * NU);  // stage dv-1
-    fetch3(B, q + 3 * STEP, o + 3 * NU);  // stage dv-2
-    for (; s >= 2; s -= 3) {
-      fetch3(C, q + 2 * STEP, o + 2 * NU);
-      stage3(A, o + 4 * NU);
-      fetch3(A, q + STEP, o + NU);
-      stage3(B, o + 3 * NU);
+    int rem = count;
+    const T* q = coef + (hi - 4) * STEP;  // pair-interleaved coefficients, see coeff_item
+    T* o = orow + (hi - 4) * opitch;
+    fetch3(A, q + 4 * STEP, o + 4 * opitch);  // stage hi
+    fetch3(B, q + 3 * STEP, o + 3 * opitch);  // stage hi-1
+    init(l);
+    for (; rem >= 3; rem -= 3) {
+      fetch3(C, q + 2 * STEP, o + 2 * opitch);
+      stage3(A, o + 4 * opitch);
+      fetch3(A, q + STEP, o + opitch);
+      stage3(B, o + 3 * opitch);
       fetch3(B, q, o);
-      stage3(C, o + 2 * NU);
-      q -= 3 * STEP, o -= 3 * NU;
+      stage3(C, o + 2 * opitch);
+      q -= 3 * STEP, o -= 3 * opitch;
     }
-    if (s >= 0) stage3(A, o + 4 * NU);
-    if (s >= 1) stage3(B, o + 3 * NU);
+    // the last rem (0..2) common stages, then the extra ones of the lanes with `more`: A and B hold the next two
+    const int post = rem + extra;  // <= 5
+    if (post > 2) fetch3(C, q + 2 * STEP, o + 2 * opitch);
+    if (post >= 1 && (rem >= 1 || more)) stage3(A, o + 4 * opitch);
+    if (post > 3) fetch3(A, q + STEP, o + opitch);
+    if (post >= 2 && (rem >= 2 || more)) stage3(B, o + 3 * opitch);
+    if (post > 4) fetch3(B, q, o);
+    if (post >= 3 && more) stage3(C, o + 2 * opitch);
+    if (post >= 4 && more) stage3(A, o + opitch);
+    if (post >= 5 && more) stage3(B, o);
+  }
+
+  // The costate recurrence is AFFINE in l once the stage coefficients are stored (l' = M_s l + b_s, dF_s = B_s l), so
+  // the horizon is cut into four chunks that run SIDE BY SIDE on the four waves instead of one lane per instance
+  // walking all dv stages:
+  //   chunk 0 (the last stages: its start value, the terminal costate, is known) is run directly;
+  //   chunks 1..3 are run from l = 0 WITH the bias (particular solution; wave 0, one lane per instance and chunk — it
+  //   writes o + sc*dF_particular to `out` like the direct lane) and from the NX unit vectors WITHOUT it (wave k:
+  //   column c of the chunk's transfer matrix on lane c*IPW + i, its dF per stage into the scratch Hd);
+  //   then l at the chunk boundaries follows from two small matrix-vector products (wave 0) and the homogeneous part
+  //   of dF, sum_c l_c(start of chunk) * Hd[stage][c], is added to `out` by all threads (one (stage, instance) each).
+  // dv stage-times of one wave become dv/4 + the remainder + ~2 short parallel phases; the result differs from the
+  // sequential recurrence by rounding only (~1e-16 relative to |l|; tests/test_gpu_parity.py bounds it against the oracle).
+  static constexpr int HL = M::NX * IPW;  // homogeneous lanes per chunk
+  // PAR is a KERNEL TEMPLATE parameter, not a run-time switch: with both forms of the sweep in one kernel (or one body
+  // with run-time chunk parameters) the register allocation of the Arnoldi loop tips over — two more spills inside the
+  // loop, each reload behind an s_waitcnt vmcnt(0), cost 5 % of the tick (measured).
+  static constexpr bool PAR_COSTATE = PAR && M::COSTATE_HOM && !LEAN && IPW == 16 && M::NX * IPW <= 64;
+  template <int MODE>
+  __device__ __forceinline__ void sweep_costate_par(T dtau, const T* xT, T* out, bool only_active) {
+    constexpr int NX = M::NX, NU = M::NU, NUL = M::NUL;
+    static_assert(NX % 2 == 0, "boundary records are read in pairs");
+    const int dv = P.dv, n = dv >> 2, n0 = dv - 3 * n;  // chunk k >= 1: stages [(3-k)n, (4-k)n); chunk 0: [3n, dv)
+    const T sc = MODE == F_PLAIN ? T(1.0) : (MODE == F_RHS ? P.one_m_zh * P.inv_h : P.inv_h);
+    T* Hd = S.scan;                             // [stage < 3n][j < NUL][c*IPW + i]
+    T* Rec = Hd + 3 * n * NUL * HL;             // boundary records [k < 3][i][REC], see scan_count
+    constexpr int REC = Lds::SCAN_REC;
+    // every address below derives from the thread index and is invariant over ticks and Arnoldi iterations: left
+    // visible, the compiler hoists those computations to the top of the kernel and keeps ~20 more values alive over the
+    // whole tick loop (they end up in scratch, reloaded behind s_waitcnt vmcnt(0))
+    int tid_o = tid;
+    asm volatile("" : "+v"(tid_o));
+    const int wave = tid_o >> 6, lane = tid_o & 63;
+    // --- phase A: all chunks side by side
+    if (wave == 0) {
+      const int i = lane & (IPW - 1), k = lane >> 4;
+      if (item_on(i, only_active)) {
+        T l[NX];
+        const int hi = k == 0 ? dv - 1 : (4 - k) * n - 1;
+        costate_run<MODE, false>(l, i, hi, n, dtau, S.R + 2 * i, out + i * P.Lp,
+                                 [&](T* l0) {
+                                   costate_terminal(l0, xT, i);
+                                   if (k != 0) {
+#pragma unroll
+                                     for (int c = 0; c < NX; ++c) l0[c] = T(0);
+                                   }
+                                 },
+                                 n0 - n, k == 0);
+        // chunk 0: its end value = the start value of chunk 1, record 0; chunk k >= 1: particular end value, record k
+        // (chunk 3's is never read and goes to the spare record)
+        T* dst = Rec + (k * IPW + i) * REC + NX * NX;
+#pragma unroll
+        for (int c = 0; c < NX; ++c) dst[c] = l[c];
+      }
+    } else if (lane < HL) {
+      const int i = lane & (IPW - 1), c0 = lane / IPW, k = wave;
+      if (item_on(i, only_active)) {
+        T l[NX];
+        costate_run<MODE, true>(l, i, (4 - k) * n - 1, n, dtau, S.R + 2 * i, Hd + lane, [&](T* l0) {
+#pragma unroll
+          for (int c = 0; c < NX; ++c) l0[c] = c == c0 ? T(1) : T(0);
+        });
+#pragma unroll
+        for (int r = 0; r < NX; ++r) Rec[(k * IPW + i) * REC + r * NX + c0] = l[r];  // column c0 of the transfer matrix
+      }
+    }
+    CGM_STAMP(*this, 16);
+    lds_barrier();
+    CGM_STAMP(*this, 17);
+    // --- phase B, all threads, no further barrier: thread (i, r) = (tid & 15, tid >> 4) owns the stages j, j + 5, ...
+    //     of chunk k = 1 + r/5 (j = r mod 5; thread 15 of an instance idles).  It walks the chunk boundaries itself —
+    //     l(start of chunk 2) = p_1 + M_1 l(start of chunk 1), l(start of chunk 3) = p_2 + M_2 l(start of chunk 2), two
+    //     NX x NX products from the records, redundantly in every thread, which is cheaper than a third barrier — and adds
+    //     sc * sum_c l_c(start of its chunk) * Hd[stage][c] to its stages of `out`.
+    {
+      const int i = tid_o & (IPW - 1), r = tid_o >> 4, k = 1 + r / 5, j0 = r - 5 * (k - 1);
+      const bool on = k <= 3 && item_on(i, only_active);
+      const Pair* rec = reinterpret_cast<const Pair*>(Rec + i * REC);  // (REC is even: records are 16-byte aligned)
+      constexpr int RP = REC / 2, KP = IPW * RP;                      // pairs per record, per chunk
+      T a[NX], al[NX];
+#pragma unroll
+      for (int c = 0; c < NX; c += 2) {
+        const Pair t = rec[(NX * NX + c) / 2];
+        a[c] = t.a, a[c + 1] = t.b;
+      }
+#pragma unroll
+      for (int c = 0; c < NX; ++c) al[c] = a[c];
+#pragma unroll
+      for (int kk = 1; kk <= 2; ++kk) {
+        T m[NX * NX], nx[NX];
+#pragma unroll
+        for (int e = 0; e < NX * NX; e += 2) {
+          const Pair t = rec[kk * KP + e / 2];
+          m[e] = t.a, m[e + 1] = t.b;
+        }
+#pragma unroll
+        for (int c = 0; c < NX; c += 2) {
+          const Pair t = rec[kk * KP + (NX * NX + c) / 2];
+          nx[c] = t.a, nx[c + 1] = t.b;
+        }
+#pragma unroll
+        for (int rr = 0; rr < NX; ++rr) {
+#pragma unroll
+          for (int c = 0; c < NX; ++c) nx[rr] = fma_t(m[rr * NX + c], a[c], nx[rr]);
+        }
+#pragma unroll
+        for (int c = 0; c < NX; ++c) {
+          a[c] = nx[c];
+          al[c] = k > kk ? nx[c] : al[c];
+        }
+        // one record in registers at a time: with both in flight the allocation of the Arnoldi loop tips into scratch
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (on) {
+        const int base = (3 - k) * n;
+        for (int j = j0; j < n; j += 5) {
+          const int s = base + j;
+#pragma unroll
+          for (int jj = 0; jj < NUL; ++jj) {
+            T acc = T(0);
+#pragma unroll
+            for (int c = 0; c < NX; ++c) acc = fma_t(al[c], Hd[(s * NUL + jj) * HL + c * IPW + i], acc);
+            T* po = out + i * P.Lp + s * NU + jj;
+            *po = fma_t(acc, sc, *po);
+          }
+        }
+      }
+    }
   }
 
   // One complete sweep on the LDS table.  COLLECTIVE: every thread of the block must call it (two workgroup barriers
@@ -1390,11 +1582,11 @@ struct WgCtx {
 };
 
 // ---- the tick kernel: cgmres.hpp:78-110 for IPW instances ----------------------------------------
-template <class M, class T, int IPW, int MAXM, bool LEAN = false>
+template <class M, class T, int IPW, int MAXM, bool LEAN = false, bool PAR = false>
 __global__ __launch_bounds__(IPW * 16) __attribute__((amdgpu_waves_per_eu(LEAN ? 2 : 1, LEAN ? 2 : 1))) void tick_wg_kernel(
     WgParams<T> P) {
   extern __shared__ __align__(16) unsigned char smem[];
-  WgCtx<M, T, IPW, MAXM, LEAN> C(P, smem);
+  WgCtx<M, T, IPW, MAXM, LEAN, PAR> C(P, smem);
   T du[MAXM], bb[MAXM];
   C.load_common(P.U);
   C.load_row_to_reg(du, P.dUdt, P.Lg);
@@ -1472,10 +1664,7 @@ __global__ __launch_bounds__(IPW * 16) __attribute__((amdgpu_waves_per_eu(LEAN ?
   }
   CGM_STAMP(C, 13);
 #ifdef CGM_STAMPS
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    g_cgm_stamps[28] += (long long)__builtin_amdgcn_s_memrealtime() - g_cgm_stamps[30];
-    g_cgm_stamps[29] += (long long)__builtin_amdgcn_s_memtime() - g_cgm_stamps[31];
-  }
+  cgm_stamp_flush();
 #endif
 }
 

@@ -31,6 +31,8 @@ struct UserDev {
   static constexpr int NUL = NU;                               // every component of dH/du may depend on the costate
   static constexpr int NBW_RAW = NX + NX * NX + NU * NX;       // dtau*q | dtau*J^T (row-major) | B^T (row-major)
   static constexpr int NBW = NBW_RAW + (NBW_RAW & 1);          // (stored in pairs)
+  static constexpr int NBW_LIN = 0;
+  static constexpr bool COSTATE_HOM = false;                   // costate sweep stays serial (WgCtx::sweep_costate_par)
   static __device__ __forceinline__ void stage_coeffs(double* bw, double* phi, const double* x, const double* u,
                                                       const double* p, const double*, double dtau) {
     double l[NX], q[NX], g[NX], hu[NU];
@@ -54,7 +56,9 @@ struct UserDev {
     if (NBW != NBW_RAW) bw[NBW - 1] = 0.0;
   }
   // l <- l + dtau*dHdx(l) and dF = B^T l_old, from the stored coefficients
+  template <bool HOM = false>  // (HOM: bias-free form of the chunk-parallel sweep, not provided here — COSTATE_HOM = false)
   static __device__ __forceinline__ void costate_step(double* l, double* dF, const double* bw, double) {
+    static_assert(!HOM, "UserDev: serial costate sweep only");
     double n[NX];
 #pragma unroll
     for (int j = 0; j < NU; ++j) {

@@ -137,7 +137,8 @@ def test_closed_loop_batch_vs_golden(path, variant, orc):
 def test_fp32_vs_fp32_reference(path, variant):
     """fp32 kernels against the fp32 build of the reference (`#define double float`), teacher-forced records:
     u, U', dUdt' and the Arnoldi count.  fp32 forward differences carry eps/h ~ 3e-5 relative noise, so dUdt' is
-    compared at 2e-3 relative and the count is not compared (the reference's own fp32-vs-fp64 counts
+    compared at 5e-3 relative (a solve that runs all k_max iterations on the noise floor lands at 2e-4 .. 3.4e-3
+    depending on the rounding of the build: seen at tick 0 of the dv = 100 case) and the count is not compared (the reference's own fp32-vs-fp64 counts
     differ on half the ticks)."""
     g = load_golden(path)
     case = g["_case"]
@@ -152,7 +153,7 @@ def test_fp32_vs_fp32_reference(path, variant):
         assert np.array_equal(u[0], u[1]) and n_ax[0] == n_ax[1]
         assert np.max(np.abs(u[0].astype(np.float64) - g[p + "u"])) <= 1e-4, (tick, u[0], g[p + "u"])
         assert np.max(np.abs(U1[0].astype(np.float64) - g[p + "U1"])) <= 1e-4, tick
-        assert dudt_close(d1[0].astype(np.float64), g[p + "dUdt1"], rel=2e-3), \
+        assert dudt_close(d1[0].astype(np.float64), g[p + "dUdt1"], rel=5e-3), \
             (tick, np.max(np.abs(d1[0] - g[p + "dUdt1"])), np.max(np.abs(g[p + "dUdt1"])))
         # the count itself is not comparable in fp32: once the residual estimate reaches the forward-difference noise
         # floor the exit test |rho_e| < 1e-6 is decided by rounding (seen: 8 here vs 20 in the fp32 reference at tick 0,

@@ -13,6 +13,10 @@ AB = os.path.join(ROOT, "_ab")  # git-ignored, but travels with gpurun (gpurun_o
 def build(name, flags, only=("capi.hip", "inst_pendulum_f64.hip")):
     d = os.path.join(AB, name); os.makedirs(d, exist_ok=True)
     srcs, _ = b.sources()
+    if os.environ.get("AB_SRC_ROOT"):  # another checkout of the sources (e.g. `git --work-tree=/tmp/old checkout HEAD -- cgmres_cpp_amd/csrc include`)
+        root = os.environ["AB_SRC_ROOT"]
+        srcs = [os.path.join(root, os.path.relpath(s, ROOT)) for s in srcs]
+        flags = flags + ["-I" + os.path.join(root, "include")]
     def cc(s):
         o = os.path.join(d, os.path.basename(s)[:-4] + ".o")
         subprocess.run([b.HIPCC] + b.CFLAGS + flags + ["-c", "-o", o, s], check=True)
@@ -32,8 +36,11 @@ else:
     for rnd in range(3):
         for n in names:
             env = dict(os.environ)
-            if n != "base":
-                env["CGMRES_HIP_LIB"] = os.path.join(AB, n, "lib.so")
+            lib, _, sw = n.partition("@")  # name@serial: CGMRES_HIP_COSTATE=serial
+            if sw:
+                env["CGMRES_HIP_COSTATE"] = sw
+            if lib != "base":
+                env["CGMRES_HIP_LIB"] = os.path.join(AB, lib, "lib.so")
             r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-ref-mode", "--steps", "150", "--warmup", "30"] + os.environ.get("AB_BENCH_ARGS", "").split(),
                                env=env, capture_output=True, text=True)
             res[n].append(json.loads(r.stdout.strip().split("\n")[-1])["ms_per_step"])
