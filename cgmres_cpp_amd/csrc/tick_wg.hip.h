@@ -1002,26 +1002,27 @@ struct WgCtx {
     CGM_STAMP(*this, 16);
     lds_barrier();
     CGM_STAMP(*this, 17);
-    // --- phase B, all threads, no further barrier: thread (i, r) = (tid & 15, tid >> 4) owns the stages j, j + 5, ...
-    //     of chunk k = 1 + r/5 (j = r mod 5; thread 15 of an instance idles).  It walks the chunk boundaries itself —
-    //     l(start of chunk 2) = p_1 + M_1 l(start of chunk 1), l(start of chunk 3) = p_2 + M_2 l(start of chunk 2), two
-    //     NX x NX products from the records, redundantly in every thread, which is cheaper than a third barrier — and adds
-    //     sc * sum_c l_c(start of its chunk) * Hd[stage][c] to its stages of `out`.
+    // --- phase B, all threads, no further barrier.  Every LDS instruction costs its issuing wave 7..16 cycles (tools/
+    //     ubench_lds.hip), so the work is dealt by WAVE such that nobody reads a boundary record it does not need:
+    //       wave 0: the stages of chunk 1 — start value = record 0, no product;
+    //       wave 1: chunk 2 — one NX x NX product, l(start of chunk 2) = p_1 + M_1 l(start of chunk 1);
+    //       waves 2, 3: chunk 3 — two products, l(start of chunk 3) = p_2 + M_2 l(start of chunk 2);
+    //     (redundantly in every thread of the wave, which is cheaper than a third barrier), then
+    //     out[stage] += sc * sum_c l_c(start of the chunk) * Hd[stage][c] for the thread's stages j, j + stride, ...
     {
-      const int i = tid_o & (IPW - 1), r = tid_o >> 4, k = 1 + r / 5, j0 = r - 5 * (k - 1);
-      const bool on = k <= 3 && item_on(i, only_active);
+      const int w = __builtin_amdgcn_readfirstlane(wave);  // (scalar: the branches below are wave-uniform)
+      const int k = w < 2 ? w + 1 : 3;
+      const int i = lane & (IPW - 1);
+      const int j0 = w < 3 ? lane >> 4 : 4 + (lane >> 4), stride = w < 2 ? 4 : 8;
       const Pair* rec = reinterpret_cast<const Pair*>(Rec + i * REC);  // (REC is even: records are 16-byte aligned)
       constexpr int RP = REC / 2, KP = IPW * RP;                      // pairs per record, per chunk
-      T a[NX], al[NX];
+      T al[NX];
 #pragma unroll
       for (int c = 0; c < NX; c += 2) {
         const Pair t = rec[(NX * NX + c) / 2];
-        a[c] = t.a, a[c + 1] = t.b;
+        al[c] = t.a, al[c + 1] = t.b;
       }
-#pragma unroll
-      for (int c = 0; c < NX; ++c) al[c] = a[c];
-#pragma unroll
-      for (int kk = 1; kk <= 2; ++kk) {
+      auto advance = [&](int kk) {  // al <- p_kk + M_kk al
         T m[NX * NX], nx[NX];
 #pragma unroll
         for (int e = 0; e < NX * NX; e += 2) {
@@ -1036,19 +1037,18 @@ struct WgCtx {
 #pragma unroll
         for (int rr = 0; rr < NX; ++rr) {
 #pragma unroll
-          for (int c = 0; c < NX; ++c) nx[rr] = fma_t(m[rr * NX + c], a[c], nx[rr]);
+          for (int c = 0; c < NX; ++c) nx[rr] = fma_t(m[rr * NX + c], al[c], nx[rr]);
         }
 #pragma unroll
-        for (int c = 0; c < NX; ++c) {
-          a[c] = nx[c];
-          al[c] = k > kk ? nx[c] : al[c];
-        }
-        // one record in registers at a time: with both in flight the allocation of the Arnoldi loop tips into scratch
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (on) {
+        for (int c = 0; c < NX; ++c) al[c] = nx[c];
+      };
+      if (k >= 2) advance(1);
+      // one record in registers at a time: with both in flight the allocation of the Arnoldi loop tips into scratch
+      __builtin_amdgcn_sched_barrier(0);
+      if (k >= 3) advance(2);
+      if (item_on(i, only_active)) {
         const int base = (3 - k) * n;
-        for (int j = j0; j < n; j += 5) {
+        for (int j = j0; j < n; j += stride) {
           const int s = base + j;
 #pragma unroll
           for (int jj = 0; jj < NUL; ++jj) {

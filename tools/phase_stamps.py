@@ -49,8 +49,8 @@ N = 100
 c.closed_loop_device(xd, ud, N); c.synchronize()
 L.cgmres_hip_debug_stamps(out)
 names = {14: "loop top: before barrier_or", 15: "barrier_or (drains V row store)", 0: "prologue loads", 1: "preamble (2 sweeps)", 3: "ring preload issue", 4: "sweep phase 1 (state)",
-         5: "sweep phase 2 (coeffs)", 20: "costate A0: terminal", 21: "costate A1: main run", 16: "costate A2: chunk 0 tail + stores", 17: "costate: barrier 1", 18: "costate B: boundaries / chunk 1",
-         19: "costate: barrier 2", 6: "sweep phase 3 (costate; C if parallel)", 7: "MGS rounds", 8: "norm+normalise+store",
+         5: "sweep phase 2 (coeffs)", 16: "costate A: four chunks side by side", 17: "costate: barrier",
+         6: "sweep phase 3 (costate; B: boundaries + combine if chunk-parallel)", 7: "MGS rounds", 8: "norm+normalise+store",
          9: "Hessenberg scalar", 10: "loop exit barrier", 11: "back-subst", 12: "x update (V*y)", 13: "epilogue"}
 tot = out[29]; wall = out[28]
 print(f"ticks {N}: shader cycles/tick {tot/N:.0f}, wall {wall/N/100:.1f} us/tick -> clock {tot/wall*100/1e3:.2f} GHz")
