@@ -126,9 +126,9 @@ def main():
         rm = remarks(rp)
         names = [m.group(1) for m in re.finditer(r"^(_Z\w+):", asm, re.M) if pat in m.group(1)]
         dm = demangle(names) if names else {}
-        for m in re.finditer(r"^(_Z\w+):.*?\.end_amdhsa_kernel", asm, re.S | re.M):
-            name = m.group(1)
-            if pat not in name:
+        for name in names:  # (by name: a device FUNCTION ahead of a kernel must not swallow it)
+            m = re.search(r"^" + re.escape(name) + r":.*?\.end_amdhsa_kernel", asm, re.S | re.M)
+            if not m:
                 continue
             lv, loops = scan(m.group(0))
             r = rm.get(name, {})
