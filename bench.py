@@ -232,6 +232,7 @@ def main():
         ctrl = cg.CgmresBatch(MODEL, batch=B, dv=DV, k_max=KMAX, tol=tol, device=local, stream=stream,
                               variant=args.variant)
         resolved["variant"] = ctrl.variant
+        resolved["variant_name"] = ctrl.variant_name
         ctrl.set_ptau_repeat(p_h)
         ctrl.init_u0(u0_h)
         ctrl.init_u0_newton(u0_h, x0_h, p_h, 10)
@@ -363,6 +364,7 @@ def main():
                    "global_batch": args.batch, "batch_per_gpu": B, "N": DV, "kmax": KMAX, "tol": args.tol,
                    "mode": "fixed-k (tol=0, every instance runs k_max Arnoldi iterations)" if args.tol == 0
                    else "reference early-exit", "variant": resolved["variant"],
+                   "variant_name": resolved["variant_name"],
                    "parallelism": f"batch-shard x{world} (fixed global batch)" +
                                   ("" if args.backend == "nccl" else " [gloo rehearsal: ranks share GPUs]"),
                    "inputs": "splitmix64(12345) perturbed x0/targets, Newton-initialised U0 (SURVEY.md §8d)"},

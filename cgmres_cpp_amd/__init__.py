@@ -27,7 +27,7 @@ SYMBOLS = [
     "cgmres_hip_model_info", "cgmres_hip_default_config", "cgmres_hip_model_probe", "cgmres_hip_register_model",
     "cgmres_hip_selftest_sincos",
     "cgmres_hip_last_error",
-    "cgmres_hip_device_count", "cgmres_hip_create", "cgmres_hip_destroy", "cgmres_hip_get_config",
+    "cgmres_hip_device_count", "cgmres_hip_create", "cgmres_hip_destroy", "cgmres_hip_get_config", "cgmres_hip_variant_name",
     "cgmres_hip_set_ptau", "cgmres_hip_set_ptau_repeat", "cgmres_hip_init_u0", "cgmres_hip_init_u0_newton",
     "cgmres_hip_control", "cgmres_hip_control_device", "cgmres_hip_closed_loop_device",
     "cgmres_hip_closed_loop_device_ptau", "cgmres_hip_synchronize",
@@ -78,6 +78,8 @@ def load():
     lib.cgmres_hip_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     lib.cgmres_hip_destroy.argtypes = [vp]
     lib.cgmres_hip_get_config.argtypes = [vp, C.POINTER(Config)]
+    lib.cgmres_hip_variant_name.argtypes = [vp]
+    lib.cgmres_hip_variant_name.restype = C.c_char_p
     lib.cgmres_hip_set_ptau.argtypes = [vp, vp, C.c_int]
     lib.cgmres_hip_set_ptau_repeat.argtypes = [vp, vp, C.c_int]
     lib.cgmres_hip_init_u0.argtypes = [vp, vp, C.c_int]
@@ -262,6 +264,7 @@ class CgmresBatch:
         _check(lib.cgmres_hip_get_config(self._h, C.byref(cfg)))  # resolved variant
         self.cfg = cfg
         self.variant = cfg.variant
+        self.variant_name = lib.cgmres_hip_variant_name(self._h).decode()  # "lane" | "wg" | "wg-lean" | "wg+parallel-costate"
         mi = model_info(self.model)
         self.dim_x, self.dim_u, self.dim_p = mi["dim_x"], mi["dim_u"], mi["dim_p"]
         self.batch, self.dv, self.k_max = cfg.batch, cfg.dv, cfg.k_max

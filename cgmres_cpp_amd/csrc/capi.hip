@@ -266,6 +266,7 @@ int cgmres_hip_get_config(cgmres_hip_handle h, cgmres_hip_config* cfg) {
   *cfg = h->cfg;
   return 0;
 }
+const char* cgmres_hip_variant_name(cgmres_hip_handle h) { return h ? h->variant_name() : nullptr; }
 int cgmres_hip_set_ptau(cgmres_hip_handle h, const void* p, int per_instance) {
   NEED(h);
   return h->set_ptau(p, per_instance, false);

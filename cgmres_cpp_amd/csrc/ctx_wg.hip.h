@@ -35,7 +35,8 @@ struct CtxWg final : cgmres_hip_ctx {
   T *x_dev = nullptr, *u_dev = nullptr;
   int fh_hbm_for_hooks = 0;
 
-  const char* variant_name() const override { return plan == PLAN_LEAN ? "wg-lean" : "wg"; }
+  bool par_costate = false;
+  const char* variant_name() const override { return plan == PLAN_LEAN ? "wg-lean" : (par_costate ? "wg+parallel-costate" : "wg"); }
 
   // (IPW, MAXM) instantiations: 16 or 8 instances per workgroup, vectors up to 160 or 320 elements; the lean LDS plan
   // (two workgroups per CU) exists for 16 instances per workgroup
@@ -139,6 +140,7 @@ struct CtxWg final : cgmres_hip_ctx {
       const size_t extra = WgLds<M, T, 16>::scan_count(cfg.dv) * sizeof(T) + 16;
       if (lds_bytes + extra <= kLdsLimit && !(e && !strcmp(e, "serial"))) par = true, lds_bytes += extra;
     }
+    par_costate = par;
     if (want == 16 && !big) pick<16, 10>(lean, par);
     if (want == 16 && big) pick<16, 20>(lean, false);
     if (want == 8 && !big) pick<8, 10>(false, false);

@@ -112,6 +112,10 @@ int cgmres_hip_device_count(void);
 int cgmres_hip_create(const cgmres_hip_config* cfg, cgmres_hip_handle* out);
 int cgmres_hip_destroy(cgmres_hip_handle h);
 int cgmres_hip_get_config(cgmres_hip_handle h, cgmres_hip_config* cfg);
+/* Name of the mapping / kernel family the handle resolved to: "lane", "wg", "wg-lean", "wg+parallel-costate" (static
+ * string; NULL on an invalid handle).  No counterpart in the reference: for logs and for tests that must know which
+ * instantiation they exercised. */
+const char* cgmres_hip_variant_name(cgmres_hip_handle h);
 
 /* ---- setup: cgmres.hpp:36-76 --------------------------------------------------------------------- */
 /* per_instance = 0: one vector broadcast to every instance; 1: [batch][...] */

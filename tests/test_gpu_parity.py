@@ -227,6 +227,63 @@ def test_seeded_batch_vs_oracle(orc, model, dv, kmax, tol, B, ticks, variant):
     c.close()
 
 
+@pytest.mark.parametrize("model,dv,kmax,tol,B", [
+    (0, 50, 10, 1e-6, 40),  # headline sizes: chunks of 12 stages, the direct chunk 14
+    (0, 49, 10, 0.0, 33),   # dv % 4 = 1
+    (0, 47, 8, 1e-6, 17),   # dv % 4 = 3
+    (0, 16, 5, 1e-6, 20),   # dv % 4 = 0, chunks of 4 stages
+    (0, 7, 3, 1e-6, 18),    # chunks of ONE stage (the look-ahead of the stage loop runs past them)
+    (0, 4, 3, 0.0, 5),      # the shortest horizon the parallel form takes
+    (2, 50, 10, 1e-6, 48),  # semiactive: dim_x = 2 -> 32 transfer-matrix lanes per chunk, 8-scalar boundary records
+    (2, 37, 6, 0.0, 19),
+    (1, 26, 6, 1e-6, 21),   # MSD with a short horizon: constant Jacobian, NBW_LIN = 0 (no coefficient fetch at all)
+    (1, 9, 4, 0.0, 16),
+])
+def test_chunk_parallel_costate_vs_serial_and_oracle(orc, model, dv, kmax, tol, B, monkeypatch):
+    """The chunk-parallel costate sweep (full plan, short vectors) against the oracle AND against the
+    serial sweep of the same library (CGMRES_HIP_COSTATE=serial picks the other kernel instantiation) at horizon
+    lengths around the chunking's edge cases.  Teacher-forced ticks, early exits included (tol > 0)."""
+    x0, u0, p = orc.batch_scenario(model, B)
+    refs = _oracle_batch(orc, model, dv, kmax, tol, x0, u0, p)
+    monkeypatch.delenv("CGMRES_HIP_COSTATE", raising=False)
+    par = cg.CgmresBatch(model, batch=B, dv=dv, k_max=kmax, tol=tol, variant=2)
+    monkeypatch.setenv("CGMRES_HIP_COSTATE", "serial")
+    ser = cg.CgmresBatch(model, batch=B, dv=dv, k_max=kmax, tol=tol, variant=2)
+    assert par.variant_name == "wg+parallel-costate" and ser.variant_name == "wg"  # (the sizes above fit its LDS scratch)
+    for c in (par, ser):
+        c.set_ptau_repeat(p)
+        c.init_u0(u0)
+        c.init_u0_newton(u0, x0, p, 10)
+    x = x0.copy()
+    for tick in range(6):
+        t_o, U_o, d_o = zip(*[r.get_state() for r in refs])
+        out = []
+        for c in (par, ser):
+            c.set_state(t_o[0], np.array(U_o), np.array(d_o))
+            u = c.control(x)
+            out.append((u, c.get_status(), c.get_state()))
+        (u_p, (k_p, why_p), (_, U_p, d_p)), (u_s, (k_s, why_s), (_, U_s, d_s)) = out
+        assert np.max(np.abs(u_p - u_s)) <= 1e-11 and np.array_equal(k_p, k_s) and np.array_equal(why_p, why_s), tick
+        assert np.max(np.abs(U_p - U_s)) <= 1e-11, tick
+        for i, r in enumerate(refs):
+            ur = r.control(x[i])
+            assert np.max(np.abs(u_p[i] - ur)) <= U_TOL, (tick, i)
+            assert k_p[i] == r.last_solve()[0] and why_p[i] == r.last_solve()[2], (tick, i)
+            assert dudt_close(d_p[i], r.get_state()[2]), (tick, i)
+            x[i] = x[i] + r.plant(x[i], ur) * r.dt
+    par.close(), ser.close()
+
+
+def test_chunk_parallel_costate_needs_its_lds_scratch():
+    """dim_u*dv = 159 with k_max = 10 leaves no room for the scratch: the handle falls back to the serial sweep."""
+    c = cg.CgmresBatch(0, batch=16, dv=53, k_max=10, tol=0.0, variant=2)
+    assert c.variant_name == "wg"
+    c.close()
+    c = cg.CgmresBatch(0, batch=16, dv=50, k_max=10, tol=0.0, variant=3)
+    assert c.variant_name == "wg-lean"
+    c.close()
+
+
 @pytest.mark.parametrize("variant", VARIANTS)
 def test_large_angles_take_the_library_trig_path(orc, variant):
     """Angles beyond the fast range of the device trig kernel (|arg| >= 1e5) make the wg sweep redo the affected
