@@ -474,8 +474,15 @@ struct WgCtx {
       // pointer advances by the same constant so the second stage of a trip addresses with immediates.
       // table/control pointers and the prefetched u0 persist across chunks (only the slow redo rewinds them)
       T* pa = tab + qi;
+#ifndef CGM_AB_MERGE_X1
+#define CGM_AB_MERGE_X1 1
+#endif
+      // MERGE_X1: the lane that holds +x1 stores it in the place of its own trig value (sin x1, which no later phase
+      // reads): one select (2 instructions) instead of a second 8-byte LDS store (14.6 cycles) per stage
+      constexpr bool MERGE_X1 = CGM_AB_MERGE_X1 != 0;
+      const bool x1_lane = rho == M::QLANE_TRUE_X;
       T* pb = pa + Q.slot_x1 * IPW;
-      T* pv = pa + Q.slot_v * IPW;
+      T* pv = pa + (MERGE_X1 && x1_lane ? 1 : Q.slot_v) * IPW;
       const T* pu = U;
       T ua = T(0);
       if (goq) ua = pu[0];
@@ -497,8 +504,12 @@ struct WgCtx {
             pa[o * STEP + M::QSLOT_XA * IPW] = x[0];
             pa[o * STEP + M::QSLOT_XB * IPW] = x[2];
           }
-          pb[o * STEP] = x[1];
-          pv[o * STEP] = v;
+          if constexpr (MERGE_X1) {
+            pv[o * STEP] = x1_lane ? x[1] : v;
+          } else {
+            pb[o * STEP] = x[1];
+            pv[o * STEP] = v;
+          }
           if constexpr (MODE == 0)
             M::quad_stage_rot(x, v, argp, u0, dtau, dtau1, Q, mc, &zmax);
           else
@@ -542,7 +553,7 @@ struct WgCtx {
           auto rewind = [&]() {
 #pragma unroll
             for (int c = 0; c < NX; ++c) x[c] = xs[c];
-            pa = tab + qi + s0 * STEP, pb = pa + Q.slot_x1 * IPW, pv = pa + Q.slot_v * IPW;
+            pa = tab + qi + s0 * STEP, pb = pa + Q.slot_x1 * IPW, pv = pa + (MERGE_X1 && x1_lane ? 1 : Q.slot_v) * IPW;
             pu = U + s0 * NU;
             ua = pu[0];
           };

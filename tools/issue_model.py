@@ -58,8 +58,8 @@ def stage_loops(asm):
         if b["depth"] == 4 and sum(o.startswith("ds_write") for o in ops) >= 4 and \
                 not any(o.startswith("v_rndne_f64") for o in ops):
             # the rotation-mode stage loop (no argument reduction); the fresh-evaluation loop (v_rndne_f64) is the fallback
-            # (the main loop does 4 stages per trip = 14 LDS operations, its remainder loop 2 = 7: keep the main one)
-            st = 2 * round(sum(o.startswith("ds_") for o in ops) / 7)
+            # (one u0 fetch per stage: the main loop does 4 stages per trip, its remainder loop 2 — keep the main one)
+            st = sum(o.startswith("ds_read") for o in ops)
             if "state" not in out or out["state"]["mode"] != "rotation" or st > out["state"]["stages_per_trip"]:
                 out["state"] = dict(label=b["label"], instructions_per_trip=len(ops), stages_per_trip=st,
                                     lds_ops=sum(o.startswith("ds_") for o in ops), mode="rotation")

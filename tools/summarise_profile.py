@@ -14,7 +14,8 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
-shutil.copy(glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0], os.path.join(dst, f"{name}_kernel_stats.csv"))
+newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)  # (gpurun merges runs into one directory: take the last one)
+shutil.copy(newest(os.path.join(src, "trace", "*", "*kernel_stats.csv")), os.path.join(dst, f"{name}_kernel_stats.csv"))
 cmd_file = os.path.join(src, "command.txt")
 out = {"command": ("python3 " + open(cmd_file).read().strip().replace(root + "/", "")) if os.path.exists(cmd_file) else
        "python3 bench.py --steps N --warmup W --no-cpu-baseline --no-ref-mode",
@@ -25,7 +26,7 @@ out["kernel"] = k["Name"]
 out["kernel_calls"] = int(k["Calls"])
 out["kernel_avg_ns"] = float(k["AverageNs"])
 for kind, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    f = glob.glob(os.path.join(src, f"pmc_{kind}", "*", "*counter_collection.csv"))[0]
+    f = newest(os.path.join(src, f"pmc_{kind}", "*", "*counter_collection.csv"))
     rows = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"] == k["Name"] and r["Counter_Name"] == ctr]
     vals = [float(r["Counter_Value"]) for r in rows]
     out[f"{ctr}_KiB_per_launch"] = sum(vals) / len(vals)
