@@ -349,11 +349,14 @@ struct PendulumDev {
   //   * the trig-dependent part of dxdt[3],  A32 x2^2 sin d + (A32a x2 - A32b u0) cos d + A52 sin x1  (model.hpp:41,
   //     regrouped), is one multiply per lane + a quad sum, bit-identical in the four lanes, so x stays replicated
   //     without any broadcast.
-  // Stage-table writes (all lanes, no branch), NSLOT = 6 slots per (stage, instance): x0, x1, x2 -> slots 0, 1, 2
-  // (x0, x2: the same value from every lane; x1 from the two x1-lanes), sin d, cos d, cos x1 -> slots 3, 4, 5.
-  // x3 is not stored: stage_coeffs does not use x[3] because q3 = 0.  The two values nobody needs — the d-lanes' -x1
-  // and sin x1 — go to slots 1 and 3 of the NEXT stage, where the proper lanes overwrite them one stage later (LDS
-  // operations of a wave complete in order); the table therefore has one pad stage after the last one (TAB_PAD).
+  // Stage-table writes (all lanes, no branch), NSLOT = 6 slots per (stage, instance): x0, x1, x2 -> slots 0, 1, 2,
+  // sin d, cos d, cos x1 -> slots 3, 4, 5.  x3 is not stored: stage_coeffs does not use x[3] because q3 = 0.  Per stage
+  // ONE 8-byte store carries four useful values: the d-lanes their sin d / cos d, the cos-x1 lane its value, and the
+  // sin-x1 lane — whose own value no later phase reads — x1 instead (WgCtx::sweep_state, MERGE_X1: one select instead of
+  // a second LDS store, which costs the issuing wave 14.6 cycles).  Without MERGE_X1 the two values nobody needs (the
+  // d-lanes' -x1 and sin x1) go to slots 1 and 3 of the NEXT stage, where the proper lanes overwrite them one stage
+  // later (LDS operations of a wave complete in order); the table therefore has one pad stage after the last one
+  // (TAB_PAD).  x0 and x2 (the same value in every lane) are written by all lanes, every other stage (see x02_step).
   static constexpr bool HAS_QUAD_SWEEP = true;
   static constexpr int NSLOT = 6, TRIG_SLOT0 = 3, TAB_PAD = 1;
   // x0 and x2 obey a recurrence of their own — x0' = x0 + dtau x2, x2' = x2 + dtau (-As x2 + Bs u0) (model.hpp:38,40) —
