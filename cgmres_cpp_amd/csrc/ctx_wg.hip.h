@@ -54,7 +54,7 @@ struct CtxWg final : cgmres_hip_ctx {
   }
   // kernels with the chunk-parallel costate sweep (WgCtx::sweep_costate_par) exist for the short-vector instantiations
   template <int MAXM>
-  static constexpr bool kParCostate = M::COSTATE_HOM && MAXM == 10 && M::NX * 16 <= 64;
+  static constexpr bool kParCostate = M::COSTATE_HOM && MAXM == 10 && M::NX * 16 <= 64 && M::NX % 2 == 0;
   static int pitch_H(int k_max) { return ((k_max * (k_max + 3)) / 2) | 1; }
   // lean plan: 16 instances per workgroup in at most half a CU's LDS; the white-box hooks keep running on the full
   // (or fh_hbm) plan of the same sizes, so that one must fit as well

@@ -961,7 +961,7 @@ struct WgCtx {
   // PAR is a KERNEL TEMPLATE parameter, not a run-time switch: with both forms of the sweep in one kernel (or one body
   // with run-time chunk parameters) the register allocation of the Arnoldi loop tips over — two more spills inside the
   // loop, each reload behind an s_waitcnt vmcnt(0), cost 5 % of the tick (measured).
-  static constexpr bool PAR_COSTATE = PAR && M::COSTATE_HOM && !LEAN && IPW == 16 && M::NX * IPW <= 64;
+  static constexpr bool PAR_COSTATE = PAR && M::COSTATE_HOM && !LEAN && IPW == 16 && M::NX * IPW <= 64 && M::NX % 2 == 0;
   template <int MODE>
   __device__ __forceinline__ void sweep_costate_par(T dtau, const T* xT, T* out, bool only_active) {
     constexpr int NX = M::NX, NU = M::NU, NUL = M::NUL;

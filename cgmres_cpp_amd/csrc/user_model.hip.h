@@ -29,10 +29,13 @@ struct UserDev {
   static constexpr bool HAS_QUAD_SWEEP = false;
   static constexpr int NSLOT = NX, TRIG_SLOT0 = NX, TAB_PAD = 0;
   static constexpr int NUL = NU;                               // every component of dH/du may depend on the costate
-  static constexpr int NBW_RAW = NX + NX * NX + NU * NX;       // dtau*q | dtau*J^T (row-major) | B^T (row-major)
-  static constexpr int NBW = NBW_RAW + (NBW_RAW & 1);          // (stored in pairs)
-  static constexpr int NBW_LIN = 0;
-  static constexpr bool COSTATE_HOM = false;                   // costate sweep stays serial (WgCtx::sweep_costate_par)
+  // coefficients of a stage: dtau*J^T (row-major) | B^T (row-major) | [pad] | dtau*q | [pad] — the entries that multiply
+  // lambda first (NBW_LIN of them, an even count: they are fetched in pairs), the bias last (PendulumDev::NBW_LIN)
+  static constexpr int NLIN_RAW = NX * NX + NU * NX;
+  static constexpr int NBW_LIN = NLIN_RAW + (NLIN_RAW & 1);
+  static constexpr int NBW_RAW = NBW_LIN + NX;
+  static constexpr int NBW = NBW_RAW + (NBW_RAW & 1);
+  static constexpr bool COSTATE_HOM = true;  // costate_step<true> exists: chunk-parallel costate sweep where it fits
   static __device__ __forceinline__ void stage_coeffs(double* bw, double* phi, const double* x, const double* u,
                                                       const double* p, const double*, double dtau) {
     double l[NX], q[NX], g[NX], hu[NU];
@@ -41,7 +44,7 @@ struct UserDev {
     Model::dHdx(q, x, u, p, l);    // costate-free parts
     Model::dHdu(phi, x, u, p, l);
 #pragma unroll
-    for (int r = 0; r < NX; ++r) bw[r] = dtau * q[r];
+    for (int r = 0; r < NX; ++r) bw[NBW_LIN + r] = dtau * q[r];
 #pragma unroll
     for (int c = 0; c < NX; ++c) {  // unit costates: column c of J^T and of B^T
       l[c] = 1.0;
@@ -49,29 +52,30 @@ struct UserDev {
       Model::dHdu(hu, x, u, p, l);
       l[c] = 0.0;
 #pragma unroll
-      for (int r = 0; r < NX; ++r) bw[NX + r * NX + c] = dtau * (g[r] - q[r]);
+      for (int r = 0; r < NX; ++r) bw[r * NX + c] = dtau * (g[r] - q[r]);
 #pragma unroll
-      for (int j = 0; j < NU; ++j) bw[NX + NX * NX + j * NX + c] = hu[j] - phi[j];
+      for (int j = 0; j < NU; ++j) bw[NX * NX + j * NX + c] = hu[j] - phi[j];
     }
+    if (NBW_LIN != NLIN_RAW) bw[NBW_LIN - 1] = 0.0;
     if (NBW != NBW_RAW) bw[NBW - 1] = 0.0;
   }
-  // l <- l + dtau*dHdx(l) and dF = B^T l_old, from the stored coefficients
-  template <bool HOM = false>  // (HOM: bias-free form of the chunk-parallel sweep, not provided here — COSTATE_HOM = false)
+  // l <- l + dtau*dHdx(l) and dF = B^T l_old, from the stored coefficients; HOM: without the bias dtau*q (one column of
+  // a chunk's transfer matrix, WgCtx::sweep_costate_par)
+  template <bool HOM = false>
   static __device__ __forceinline__ void costate_step(double* l, double* dF, const double* bw, double) {
-    static_assert(!HOM, "UserDev: serial costate sweep only");
     double n[NX];
 #pragma unroll
     for (int j = 0; j < NU; ++j) {
       double a = 0.0;
 #pragma unroll
-      for (int c = 0; c < NX; ++c) a += bw[NX + NX * NX + j * NX + c] * l[c];
+      for (int c = 0; c < NX; ++c) a += bw[NX * NX + j * NX + c] * l[c];
       dF[j] = a;
     }
 #pragma unroll
     for (int r = 0; r < NX; ++r) {
-      double a = l[r] + bw[r];
+      double a = HOM ? l[r] : l[r] + bw[NBW_LIN + r];
 #pragma unroll
-      for (int c = 0; c < NX; ++c) a += bw[NX + r * NX + c] * l[c];
+      for (int c = 0; c < NX; ++c) a += bw[r * NX + c] * l[c];
       n[r] = a;
     }
 #pragma unroll
