@@ -42,8 +42,7 @@ MODEL, MODEL_ID, DV, KMAX = "pendulum", 0, 50, 10
 DIM_X, DIM_U, DIM_P = 4, 3, 2
 GLOBAL_BATCH = 4096
 # rocprofv3 PMC summary of this same command (tools/profile_bench.sh + tools/summarise_profile.py), newest first
-PMC_SUMMARIES = [os.path.join(ROOT, "profiles", n) for n in ("r02_wg_bench_pmc.json", "r01_v10_wg_bench_pmc.json")]
-ISSUE_MODEL = os.path.join(ROOT, "profiles", "r02_issue_model.json")
+ISSUE_MODELS = [os.path.join(ROOT, "profiles", n) for n in ("r03_issue_model.json", "r02_issue_model.json")]
 
 
 def algorithmic_bytes(k, L=DIM_U * DV, scalar=8):
@@ -88,79 +87,66 @@ def cpu_baseline(batch, tol, warm, seconds_budget):
 
 
 def committed_traffic(kernel_variant, ticks_per_launch, batch):
-    """HBM bytes per launch from the COMMITTED rocprofv3 PMC passes of this command (not measured in this run)."""
-    if kernel_variant != 2 or batch != GLOBAL_BATCH:
+    """HBM bytes per launch from the COMMITTED rocprofv3 PMC passes of this command at this per-GPU batch (not measured
+    in this run): profiles/r<NN>_wg_bench[_B<batch>]_pmc.json, newest round first."""
+    import glob
+    import re
+    if kernel_variant not in (2, 3):
         return None, None
-    for path in PMC_SUMMARIES:
+    cands = []
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r*_wg_bench*_pmc.json")):
+        m = re.match(r"r(\d+)_wg_bench(?:_B(\d+))?_pmc\.json$", os.path.basename(path))
+        if m and int(m.group(2) or GLOBAL_BATCH) == batch:
+            cands.append((int(m.group(1)), path))
+    for _, path in sorted(cands, reverse=True):
         try:
             s = json.load(open(path))
-        except OSError:
+        except (OSError, ValueError):
             continue
-        if "tick_wg_kernel" in s.get("kernel", "") and s.get("ticks_per_launch", 1) == ticks_per_launch:
+        lean = "true, " in s.get("kernel", "").split("16, 10,")[-1][:8]  # <..., 16, 10, LEAN, PAR>
+        if "tick_wg_kernel" in s.get("kernel", "") and s.get("ticks_per_launch", 1) == ticks_per_launch \
+                and lean == (kernel_variant == 3):
             return s["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
     return None, None
 
 
-class ParityError(RuntimeError):
-    pass
+from tests.parity_gate import OracleSample, ParityError, gate_continuation, sample_of  # noqa: E402  (the checker)
 
 
-def sample_of(B, n):
-    step = max(1, B // n)
-    s = list(range(0, B, step))[:n]
-    for extra in (B - 1, 15, 16):
-        if 0 <= extra < B and extra not in s:
-            s.append(extra)
-    return sorted(s)
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
 
-class OracleSample:
-    """Checker for a spread sample of this rank's instances (oracle = test infrastructure, used as the checker only)."""
+def launcher_command(script, n, argv, port):
+    """The command `python3 <script> --gpus N ...` turns into when it was started WITHOUT torch.distributed.run:
+    one rank per GPU of this node, rendezvous on 127.0.0.1 (the container's hostname may not resolve)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
 
-    def __init__(self, tol, x0, u0, p, n):
-        from oracle import orc
-        if not os.path.exists(orc.ORACLE_SO):
-            orc.build(ref=False)
-        self.orc = orc
-        self.idx = sample_of(len(x0), n)
-        self.x = [x0[i].copy() for i in self.idx]
-        self.ctrls = []
-        for i in self.idx:
-            c = orc.Controller(orc.PENDULUM, DV, KMAX, tol)
-            orc.start_controller(c, x0[i], u0[i], p[i])
-            self.ctrls.append(c)
-        self.u = [None] * len(self.idx)
 
-    def advance(self, ticks):
-        for j, c in enumerate(self.ctrls):
-            for _ in range(ticks):
-                u = c.control(self.x[j])
-                self.x[j] = self.x[j] + c.plant(self.x[j], u) * c.dt
-                self.u[j] = u
-
-    def adopt(self, t, U, dUdt, x):
-        """Teacher forcing: take over the device's controller and plant state."""
-        for j, i in enumerate(self.idx):
-            self.ctrls[j].set_state(t, U[i], dUdt[i])
-            self.x[j] = x[i].copy()
-
-    def compare(self, what, x, u, n_ax, tol_u, strict_counts):
-        """max error of u and x over the sample; Arnoldi counts must be equal (in early-exit mode a differing count
-        is reported instead: the exit test can sit within rounding of tol)"""
-        worst = 0.0
-        self.flips = 0
-        for j, i in enumerate(self.idx):
-            du = float(np.max(np.abs(u[i] - self.u[j])))
-            dx = float(np.max(np.abs(x[i] - self.x[j])))
-            worst = max(worst, du, dx)
-            if not (du <= tol_u and dx <= tol_u):
-                raise ParityError(f"{what}: instance {i}: |du| = {du:.3e}, |dx| = {dx:.3e} > {tol_u:g}")
-            k_o = self.ctrls[j].last_solve()[0]
-            if n_ax[i] != k_o:
-                if strict_counts:
-                    raise ParityError(f"{what}: instance {i}: Arnoldi count {n_ax[i]} vs oracle {k_o}")
-                self.flips += 1
-        return worst
+def self_launch(script, n, argv):
+    """--gpus N > 1 from a plain `python3 bench.py`: start the N ranks as a CHILD process (never an exec: this runs
+    before anything has touched torch or HIP, and the child is a fresh interpreter), relay its stdout — rank 0's one
+    JSON line — and hand back its return code."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = launcher_command(script, n, argv, _free_port())
+    if os.environ.get("CGMRES_BENCH_PRINT_LAUNCH"):  # tests: show the child command instead of running it
+        print(json.dumps({"launch": cmd}), flush=True)
+        return 0
+    sys.stderr.write("[bench] --gpus %d without WORLD_SIZE: launching %s\n" % (n, " ".join(cmd)))
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in child.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return child.wait()
 
 
 def main():
@@ -173,7 +159,8 @@ def main():
     ap.add_argument("--tol", type=float, default=0.0,
                     help="0 = fixed-k mode (always k_max Arnoldi iterations, deterministic work; headline); "
                          "1e-6 = the reference's early-exit mode")
-    ap.add_argument("--variant", type=int, default=0, help="kernel mapping: 0 default, 1 lane, 2 wg")
+    ap.add_argument("--variant", type=int, default=0,
+                    help="kernel mapping: 0 = the library's choice, 1 lane, 2 wg, 3 wg-lean (two workgroups per CU)")
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall budget of each timed CPU-baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ref-mode", action="store_true", help="skip the secondary tol=1e-6 measurement")
@@ -182,7 +169,15 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real thing); gloo = rehearsal of the N > 1 path on a box with fewer "
                          "GPUs than ranks (ranks share devices, collectives go through host tensors)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous only: every rank joins the process group, rank 0 prints the world it sees (the "
+                         "CPU rehearsal of the N > 1 entry; needs no GPU)")
     args = ap.parse_args()
+
+    # N > 1 started like N = 1 (no torch.distributed.run around it): become the launcher.  Decided BEFORE torch is
+    # imported, so the parent never initialises the GPU.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(os.path.abspath(__file__), args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -196,7 +191,22 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit(f"--gpus {args.gpus} but WORLD_SIZE = {world}: launch with torch.distributed.run "
-                 f"--nproc-per-node {args.gpus}")
+                 f"--nproc-per-node {args.gpus} (or plain `python3 bench.py --gpus {args.gpus}`, which does that itself)")
+    if args.launch_check:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo")
+            seen = [None] * world
+            dist.all_gather_object(seen, (rank, local))
+            dist.barrier()
+        else:
+            seen = [(0, 0)]
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "world_size": dist.get_world_size() if world > 1 else 1,
+                              "ranks": sorted(r for r, _ in seen), "gpus": args.gpus}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: there is no CPU path")
     if args.backend == "gloo":
@@ -238,7 +248,7 @@ def main():
         ctrl.init_u0_newton(u0_h, x0_h, p_h, 10)
         x = torch.from_numpy(x0_h).to(dev)
         u = torch.zeros(B, DIM_U, dtype=torch.float64, device=dev)
-        chk = OracleSample(tol, x0_h, u0_h, p_h, check) if check else None
+        chk = OracleSample(MODEL, DV, KMAX, tol, x0_h, u0_h, p_h, check) if check else None
         parity = {}
         ctrl.closed_loop_device(x, u, warmup)
         torch.cuda.synchronize()
@@ -252,7 +262,7 @@ def main():
                 parity["arnoldi_count_flips"] = chk.flips
         except ParityError as e:
             err = str(e)
-        walls, kernels = [], []
+        walls, kernels, own = [], [], []
         for _ in range(reps):
             torch.cuda.synchronize()
             if world > 1:
@@ -267,6 +277,7 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
             wall = time.perf_counter() - t0
+            own.append(kernel_ms)
             tt = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=cdev)
             if world > 1:
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -281,23 +292,9 @@ def main():
                 # builds (measured on this scenario around tick 320, where |u| reaches its bound: x1e5 within 11 ticks
                 # for ~1 % of the instances while every single tick agrees to 2e-14 — tools/accuracy_scan.py), so the
                 # free-running 10 ticks are held to 1e-6: far below anything a hand-over bug produces, above the chaos.
-                t_dev, U_dev, d_dev = ctrl.get_state()
-                chk.adopt(t_dev, U_dev, d_dev, x.cpu().numpy())
-                ctrl.closed_loop_device(x, u, 1)
-                torch.cuda.synchronize()
-                chk.advance(1)
-                parity["continuation_1tick_max_err"] = chk.compare(
-                    "one teacher-forced tick from the timed state", x.cpu().numpy(), u.cpu().numpy(),
-                    ctrl.get_status()[0], 1e-9, tol == 0.0)
-                flips = chk.flips
-                ctrl.closed_loop_device(x, u, 10)
-                torch.cuda.synchronize()
-                chk.advance(10)
-                parity["continuation_10tick_fused_max_err"] = chk.compare(
-                    "10 fused ticks after the timed state", x.cpu().numpy(), u.cpu().numpy(), ctrl.get_status()[0],
-                    1e-6, False)
-                parity["arnoldi_count_flips"] = parity.get("arnoldi_count_flips", 0) + flips + chk.flips
-                parity["instances_checked"] = len(chk.idx)
+                flips0 = parity.get("arnoldi_count_flips", 0)
+                parity.update(gate_continuation(ctrl, chk, x, u, torch.cuda.synchronize, 1e-9, 1e-6, tol == 0.0))
+                parity["arnoldi_count_flips"] += flips0
         except ParityError as e:
             err = str(e)
         ctrl.close()
@@ -311,8 +308,13 @@ def main():
                 dist.destroy_process_group()
             sys.exit("parity check against the oracle failed: refusing to report a number")
         med = statistics.median_low(walls)
+        # every rank's own HIP-event time of the median repetition (the line's time is the max over ranks)
+        mine = torch.tensor([own[walls.index(med)]], dtype=torch.float64, device=cdev)
+        per_rank = [torch.zeros_like(mine) for _ in range(world)] if world > 1 else [mine]
+        if world > 1:
+            dist.all_gather(per_rank, mine)
         return {"B": B, "wall": med, "kernel_ms": kernels[walls.index(med)], "walls": walls, "n_ax": n_ax,
-                "parity": parity}
+                "parity": parity, "rank_kernel_ms": [t.item() for t in per_rank]}
 
     n_check = args.check_sample if world == 1 else max(8, args.check_sample // world)
     inputs = shard_inputs(args.batch)
@@ -321,7 +323,7 @@ def main():
     value = args.batch * args.steps / m["wall"]
     ms_per_step = m["wall"] * 1e3 / args.steps
     # one launch of the wg mapping = TICKS_PER_LAUNCH consecutive ticks of the batch (the lane mapping: one tick)
-    tpl = cg.TICKS_PER_LAUNCH if resolved["variant"] == 2 else 1
+    tpl = cg.TICKS_PER_LAUNCH if resolved["variant"] in (2, 3) else 1  # (3 = wg-lean: same kernel, half the LDS)
     n_launches = -(-args.steps // tpl)
     launch_ms = m["kernel_ms"] / n_launches
     bytes_per_tick = float(sum(algorithmic_bytes(int(k)) for k in m["n_ax"])) if args.tol > 0 else \
@@ -343,23 +345,27 @@ def main():
         weak = {"scaling": "weak", "batch_per_gpu": mw["B"], "global_batch": args.batch * world,
                 "value": args.batch * world * args.steps / mw["wall"], "ms_per_step": mw["wall"] * 1e3 / args.steps}
 
-    kernel_name = {1: "tick_lane_kernel", 2: "tick_wg_kernel"}[resolved["variant"]]
+    kernel_name = "tick_lane_kernel" if resolved["variant"] == 1 else f"tick_wg_kernel [{resolved['variant_name']}]"
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source_committed_profile": traffic_src,
                 "measured_GBps": (traffic / (launch_ms * 1e-3) / 1e9) if traffic else None,
                 "kernel": f"{kernel_name} ({tpl} control step(s) of the batch per launch)", "launch_ms": launch_ms,
                 "ticks_per_launch": args.steps / n_launches, "algorithmic_bytes_per_launch": bytes_per_launch,
                 "rank": 0, "instances_per_launch": B}
-    try:
-        roofline["issue_slot_model"] = json.load(open(ISSUE_MODEL))
-    except OSError:
-        pass
+    for path in ISSUE_MODELS:
+        try:
+            roofline["issue_slot_model"] = json.load(open(path))
+            break
+        except OSError:
+            pass
     out = {
         "metric": "C/GMRES control steps/sec, batch=4096 N=50 kmax=10; HBM GB/s vs roofline",
         "value": value, "unit": "control steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic", "reps": args.reps,
         "rep_ms_per_step": [w * 1e3 / args.steps for w in m["walls"]],
+        "world_size": dist.get_world_size() if world > 1 else 1,
+        "rank_ms_per_step": [t / args.steps for t in m["rank_kernel_ms"]],
         "config": {"workload": "arm_type_inverted_pendulum controllers, closed loop with on-device Euler plant",
                    "global_batch": args.batch, "batch_per_gpu": B, "N": DV, "kmax": KMAX, "tol": args.tol,
                    "mode": "fixed-k (tol=0, every instance runs k_max Arnoldi iterations)" if args.tol == 0

@@ -59,3 +59,53 @@ def test_multiple_controller_shares_cus_only_when_needed(monkeypatch):
     asked.clear()
     multi.MultipleController([dict(model="msd", batch=8192)])
     assert asked == [0]                         # a single member: the library's own choice
+
+
+# ---- the N > 1 entry: `python3 bench.py --gpus N` from a plain invocation starts its own torch.distributed.run ----
+def _run_plain(script, *argv, env=None, timeout=300):
+    import subprocess
+    import sys
+    e = dict(os.environ, **(env or {}))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        e.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, script)] + list(argv), env=e, capture_output=True,
+                          text=True, timeout=timeout, cwd="/tmp")
+
+
+def test_bench_gpus_n_launches_its_own_ranks_command_line():
+    import json
+    import sys
+    for script, extra in (("bench.py", ["--steps", "20", "--warmup", "10"]),
+                          (os.path.join("tools", "bench_configs.py"), ["--config", "4"])):
+        r = _run_plain(script, "--gpus", "4", *extra, env={"CGMRES_BENCH_PRINT_LAUNCH": "1"})
+        assert r.returncode == 0, r.stderr[-2000:]
+        cmd = json.loads(r.stdout.strip().splitlines()[-1])["launch"]
+        assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+        assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+        assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+        k = cmd.index(os.path.join(ROOT, script))          # the script itself, then its own arguments unchanged
+        assert cmd[k + 1:] == ["--gpus", "4"] + extra
+        assert "torch" not in r.stderr.lower() or "launching" in r.stderr  # the parent never got as far as importing torch
+
+
+def test_bench_gpus_2_from_a_plain_invocation_reaches_a_world_of_two():
+    """No GPU needed: --launch-check stops after the rendezvous (gloo).  The parent relays rank 0's line and the
+    children's return code."""
+    import json
+    r = _run_plain("bench.py", "--gpus", "2", "--backend", "gloo", "--launch-check")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line == {"launch_check": True, "world_size": 2, "ranks": [0, 1], "gpus": 2}
+    # a failing child is reported, not swallowed (no GPU here: the real bench refuses to run)
+    r = _run_plain("bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "10")
+    assert r.returncode != 0
+
+
+def test_bench_handles_every_wg_variant_in_its_bookkeeping():
+    b = _bench()
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'resolved["variant"] in (2, 3)' in src          # wg-lean fuses 10 ticks per launch like wg
+    # committed PMC traffic is looked up per per-GPU batch and per LDS plan
+    t, path = b.committed_traffic(2, 10, 4096)
+    assert t and path.startswith("profiles/")
+    assert b.committed_traffic(1, 1, 4096) == (None, None)

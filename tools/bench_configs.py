@@ -3,7 +3,13 @@
 the example plants, fixed-k mode (tol = 0) and reference mode (tol = 1e-6).
 
     python tools/bench_configs.py [--config all|1|2|3|4|5|headline] [--steps K] [--warmup W] > gpurun_out/configs.jsonl
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/bench_configs.py --config 4
+    python tools/bench_configs.py --gpus N --config 4        (N > 1: starts its own torch.distributed.run child, like bench.py)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/bench_configs.py --gpus N --config 4
+
+Every line is parity-gated before it is printed (tests/parity_gate.py, the oracle as the checker, outside the timed
+region): a spread sample of EVERY member's instances is continued from the state the timed region left behind — one
+teacher-forced tick at 1e-9 (fp32 members: 1e-4 against the fp32 oracle), then 10 fused free-running ticks at 1e-6
+(fp32: 2e-3) — and the script refuses to print a number on mismatch.
 
 Config 4 (multiple_controller: 4096 Model1 = MSD + 4096 Model2 = pendulum controllers, both N = 50) under
 torch.distributed: EACH model's sub-batch is split over all ranks (cgmres_cpp_amd.sharding.shard_bounds — an MSD tick
@@ -21,13 +27,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-import cgmres_cpp_amd as cg  # noqa: E402
-from cgmres_cpp_amd import scenarios  # noqa: E402
-from cgmres_cpp_amd.multi import MultipleController  # noqa: E402
-from cgmres_cpp_amd.sharding import shard_bounds  # noqa: E402
 
 NAMES = {0: "pendulum", 1: "msd", 2: "semiactive"}
 DIMS = {0: (4, 3, 2), 1: (4, 6, 2), 2: (2, 3, 0)}
@@ -51,10 +50,25 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--tols", default="0,1e-6")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal with ranks sharing GPUs")
+    ap.add_argument("--gpus", type=int, default=0, help="ranks (one per GPU); 0 = whatever WORLD_SIZE says (1 without it)")
+    ap.add_argument("--check-sample", type=int, default=24, help="instances per member and rank checked against the oracle")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # before torch is imported: the parent never touches the GPU
+        from bench import self_launch
+        sys.exit(self_launch(os.path.abspath(__file__), args.gpus, sys.argv[1:]))
+
+    import torch
+    import torch.distributed as dist
+
+    from cgmres_cpp_amd import scenarios
+    from cgmres_cpp_amd.multi import MultipleController
+    from cgmres_cpp_amd.sharding import shard_bounds
+    from tests.parity_gate import OracleSample, ParityError, gate_continuation
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus and args.gpus != world:
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE = {world}")
     if args.backend == "gloo":
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
@@ -83,10 +97,11 @@ def main():
             shards.append((lo, hi))
         mc = MultipleController(specs, device=local)  # (creates one stream per member, alternating priorities)
         tdt = torch.float64 if dtype == "f64" else torch.float32
-        xs, us = [], []
+        xs, us, hosts = [], [], []
         for m, (model, Bg, dv, kmax), (lo, hi) in zip(mc.members, members, shards):
             x0, u0, p = scenarios.batch(NAMES[model], Bg)  # seeded: every rank draws the job and keeps its slice
             x0, u0, p = x0[lo:hi], u0[lo:hi], p[lo:hi]
+            hosts.append((x0, u0, p))
             if DIMS[model][2]:
                 m.set_ptau_repeat(p)
             m.init_u0(u0)
@@ -115,14 +130,36 @@ def main():
             dist.all_reduce(by, op=dist.ReduceOp.SUM)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         variants = [m.variant for m in mc.members]
+        # parity gate (outside the timed region): every member, from the state the timed region left behind, with the
+        # OTHER members' kernels still co-resident for the fused ticks (the joint mode is what was timed)
+        gate, err = [], None
+        f32 = dtype == "f32"
+        try:
+            if args.check_sample:
+                for m, (model, Bg, dv, kmax), (x0, u0, p), x, u in zip(mc.members, members, hosts, xs, us):
+                    chk = OracleSample(model, dv, kmax, tol, x0, u0, p, args.check_sample, dtype)
+                    gate.append(gate_continuation(m, chk, x, u, mc.synchronize, 1e-4 if f32 else 1e-9,
+                                                  2e-3 if f32 else 1e-6, tol == 0.0 and not f32))
+        except ParityError as e:
+            err = str(e)
+        bad = torch.tensor([0 if (err is None and ok.item()) else 1], dtype=torch.int32, device=cdev)
+        if world > 1:
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
         mc.close()
+        if err is not None:
+            sys.stderr.write(f"[rank {rank}] PARITY FAILURE ({label}, tol={tol:g}): {err}\n")
+        if bad.item():
+            if world > 1:
+                dist.destroy_process_group()
+            sys.exit("parity check against the oracle failed: refusing to report a number")
         total = sum(b for _, b, _, _ in members)
         ms = tt.item() / args.steps * 1e3
         out = {"config": label, "members": [f"{NAMES[m]} B={b} dv={dv} k={k}" for m, b, dv, k in members], "dtype": dtype,
                "tol": tol, "n_gpus": world, "variants": variants, "ms_per_tick": ms,
                "steps_per_s": total * args.steps / tt.item(), "mean_arnoldi_last_tick_rank0": kmean,
                "algorithmic_GBps": by.item() / (ms * 1e-3) / 1e9,
-               "frac_of_8TBps_per_gpu": by.item() / (ms * 1e-3) / 1e9 / 8000.0 / world, "finite": bool(ok.item())}
+               "frac_of_8TBps_per_gpu": by.item() / (ms * 1e-3) / 1e9 / 8000.0 / world, "finite": bool(ok.item()),
+               "parity_rank0": gate}
         if rank == 0:
             print(json.dumps(out), flush=True)
 
