@@ -161,6 +161,7 @@ def main():
                          "1e-6 = the reference's early-exit mode")
     ap.add_argument("--variant", type=int, default=0,
                     help="kernel mapping: 0 = the library's choice, 1 lane, 2 wg, 3 wg-lean (two workgroups per CU)")
+    ap.add_argument("--flags", type=int, default=0, help="cgmres_hip_config.flags (A/B measurements; 0 = library defaults)")
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall budget of each timed CPU-baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ref-mode", action="store_true", help="skip the secondary tol=1e-6 measurement")
@@ -240,7 +241,7 @@ def main():
         x0_h, u0_h, p_h = inputs
         B = len(x0_h)
         ctrl = cg.CgmresBatch(MODEL, batch=B, dv=DV, k_max=KMAX, tol=tol, device=local, stream=stream,
-                              variant=args.variant)
+                              variant=args.variant, flags=args.flags)
         resolved["variant"] = ctrl.variant
         resolved["variant_name"] = ctrl.variant_name
         ctrl.set_ptau_repeat(p_h)

@@ -18,8 +18,9 @@ PENDULUM, MSD, SEMIACTIVE = 0, 1, 2
 MODEL_IDS = {"pendulum": PENDULUM, "arm_type_inverted_pendulum": PENDULUM, "msd": MSD,
              "mass_spring_damper": MSD, "semiactive": SEMIACTIVE, "semiactive_damper": SEMIACTIVE}
 F64, F32 = 0, 1
-EXIT_NATURAL, EXIT_CONVERGED, EXIT_SMALL_RESIDUAL, EXIT_BREAKDOWN = 0, 1, 2, 3
-ABI_VERSION = 1
+EXIT_NATURAL, EXIT_CONVERGED, EXIT_SMALL_RESIDUAL, EXIT_BREAKDOWN, EXIT_NONFINITE = 0, 1, 2, 3, 4
+FLAG_SERIAL_COSTATE, FLAG_IPW8, FLAG_NO_BINNING = 1, 2, 4
+ABI_VERSION = 2
 TICKS_PER_LAUNCH = 10  # CGMRES_HIP_TICKS_PER_LAUNCH: closed_loop_device fuses this many ticks per launch (wg mapping)
 
 # every symbol include/cgmres_hip.h declares (tests/test_capi_symbols.py checks header == this == library)
@@ -42,7 +43,7 @@ class Config(C.Structure):
     """struct cgmres_hip_config (include/cgmres_hip.h)."""
     _fields_ = [("abi_version", C.c_int32), ("model_id", C.c_int32), ("dtype", C.c_int32), ("batch", C.c_int32),
                 ("dv", C.c_int32), ("k_max", C.c_int32), ("device", C.c_int32), ("variant", C.c_int32),
-                ("tol", C.c_double), ("dt", C.c_double), ("h", C.c_double), ("zeta", C.c_double),
+                ("flags", C.c_int32), ("reserved", C.c_int32), ("tol", C.c_double), ("dt", C.c_double), ("h", C.c_double), ("zeta", C.c_double),
                 ("Tf", C.c_double), ("alpha", C.c_double), ("stream", C.c_void_p)]
 
 
@@ -237,7 +238,7 @@ class CgmresBatch:
     """
 
     def __init__(self, model, batch=1, dv=None, k_max=None, tol=None, dtype="f64", device=0, stream=None,
-                 variant=0, **tuning):
+                 variant=0, flags=0, **tuning):
         lib = load()
         self.model = MODEL_IDS.get(model, model)
         cfg = Config()
@@ -256,6 +257,7 @@ class CgmresBatch:
             setattr(cfg, k, float(v))
         cfg.device = int(device)
         cfg.variant = int(variant)
+        cfg.flags = int(flags)
         cfg.stream = stream
         self._h = None
         h = C.c_void_p()

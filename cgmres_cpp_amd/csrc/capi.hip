@@ -141,29 +141,38 @@ int cgmres_hip_model_probe(int32_t model_id, int32_t device, const double* x, co
   double* d = nullptr;
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), (n_in + n_out + 1) * sizeof(double)));
   double *dx = d, *du = dx + mi.dim_x, *dp = du + mi.dim_u, *dl = dp + mi.dim_p, *dout = dl + mi.dim_x;
-  (void)hipMemcpy(dx, x, mi.dim_x * 8, hipMemcpyHostToDevice);
-  (void)hipMemcpy(du, u, mi.dim_u * 8, hipMemcpyHostToDevice);
-  if (mi.dim_p) (void)hipMemcpy(dp, p, mi.dim_p * 8, hipMemcpyHostToDevice);
-  (void)hipMemcpy(dl, lmd, mi.dim_x * 8, hipMemcpyHostToDevice);
-  if (const Plugin* pl = find_plugin(model_id)) {
-    if (pl->probe(dx, du, dp, dl, dout, nullptr) != 0) {
-      (void)hipFree(d);
-      return fail(CGMRES_HIP_ERUNTIME, "model_probe: plugin kernel launch failed");
+  // every step is checked: the facade's model fingerprint (include/cgmres.hpp) trusts `out` to pick a device model
+  hipError_t e = hipMemcpy(dx, x, mi.dim_x * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(du, u, mi.dim_u * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess && mi.dim_p) e = hipMemcpy(dp, p, mi.dim_p * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dl, lmd, mi.dim_x * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(dout, 0xff, n_out * 8);  // (NaN pattern: a kernel that did not run cannot pass for a match)
+  const char* what = "copy in";
+  if (e == hipSuccess) {
+    what = "kernel";
+    if (const Plugin* pl = find_plugin(model_id)) {
+      if (pl->probe(dx, du, dp, dl, dout, nullptr) != 0) e = hipErrorLaunchFailure;
+    } else {
+      switch (model_id) {
+        case CGMRES_HIP_MODEL_PENDULUM:
+          cgm::probe_kernel<cgm::PendulumDev<double>><<<1, 1>>>(dx, du, dp, dl, dout);
+          break;
+        case CGMRES_HIP_MODEL_MSD:
+          cgm::probe_kernel<cgm::MsdDev<double>><<<1, 1>>>(dx, du, dp, dl, dout);
+          break;
+        default:
+          cgm::probe_kernel<cgm::SemiactiveDev<double>><<<1, 1>>>(dx, du, dp, dl, dout);
+      }
+      e = hipGetLastError();
     }
-  } else
-  switch (model_id) {
-    case CGMRES_HIP_MODEL_PENDULUM:
-      cgm::probe_kernel<cgm::PendulumDev<double>><<<1, 1>>>(dx, du, dp, dl, dout);
-      break;
-    case CGMRES_HIP_MODEL_MSD:
-      cgm::probe_kernel<cgm::MsdDev<double>><<<1, 1>>>(dx, du, dp, dl, dout);
-      break;
-    default:
-      cgm::probe_kernel<cgm::SemiactiveDev<double>><<<1, 1>>>(dx, du, dp, dl, dout);
+    if (e == hipSuccess) e = hipDeviceSynchronize();  // (execution errors of the probe kernel surface here)
   }
-  hipError_t e = hipMemcpy(out, dout, n_out * 8, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) {
+    what = "copy out";
+    e = hipMemcpy(out, dout, n_out * 8, hipMemcpyDeviceToHost);
+  }
   (void)hipFree(d);
-  if (e != hipSuccess) return fail(CGMRES_HIP_ERUNTIME, "model_probe: %s", hipGetErrorString(e));
+  if (e != hipSuccess) return fail(CGMRES_HIP_ERUNTIME, "model_probe (%s): %s", what, hipGetErrorString(e));
   return 0;
 }
 
@@ -173,9 +182,13 @@ int cgmres_hip_selftest_sincos(int32_t device, const double* a, int32_t n, doubl
   HIP_TRY(hipSetDevice(device));
   double* d = nullptr;
   HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d), size_t(3) * (n ? n : 1) * sizeof(double)));
-  (void)hipMemcpy(d, a, size_t(n) * 8, hipMemcpyHostToDevice);
-  sincos_selftest_kernel<<<(n + 255) / 256, 256>>>(d, d + n, d + 2 * size_t(n), n);
-  hipError_t e = hipMemcpy(s, d + n, size_t(n) * 8, hipMemcpyDeviceToHost);
+  hipError_t e = hipMemcpy(d, a, size_t(n) * 8, hipMemcpyHostToDevice);
+  if (e == hipSuccess && n > 0) {
+    sincos_selftest_kernel<<<(n + 255) / 256, 256>>>(d, d + n, d + 2 * size_t(n), n);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+  }
+  if (e == hipSuccess) e = hipMemcpy(s, d + n, size_t(n) * 8, hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(c, d + 2 * size_t(n), size_t(n) * 8, hipMemcpyDeviceToHost);
   (void)hipFree(d);
   if (e != hipSuccess) return fail(CGMRES_HIP_ERUNTIME, "selftest_sincos: %s", hipGetErrorString(e));
@@ -240,6 +253,8 @@ int cgmres_hip_create(const cgmres_hip_config* cfg, cgmres_hip_handle* out) {
     return fail(CGMRES_HIP_EINVAL, "dim_u*dv = %ld with k_max = %d exceeds the reference's 16-bit index range", len, cfg->k_max);
   if (!(cfg->h > 0) || !(cfg->dt > 0) || !(cfg->tol >= 0)) return fail(CGMRES_HIP_EINVAL, "h, dt must be > 0 and tol >= 0");
   if (cfg->variant < 0 || cfg->variant > 3) return fail(CGMRES_HIP_EINVAL, "unknown variant %d", cfg->variant);
+  if (cfg->flags & ~(CGMRES_HIP_FLAG_SERIAL_COSTATE | CGMRES_HIP_FLAG_IPW8 | CGMRES_HIP_FLAG_NO_BINNING))
+    return fail(CGMRES_HIP_EINVAL, "unknown flags 0x%x", cfg->flags);
   if (int rc = check_device(cfg->device)) return rc;
   int resolved = 0;
   cgmres_hip_ctx* c = make_ctx(*cfg, &resolved);

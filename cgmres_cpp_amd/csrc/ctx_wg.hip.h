@@ -56,13 +56,25 @@ struct CtxWg final : cgmres_hip_ctx {
   template <int MAXM>
   static constexpr bool kParCostate = M::COSTATE_HOM && MAXM == 10 && M::NX * 16 <= 64 && M::NX % 2 == 0;
   static int pitch_H(int k_max) { return ((k_max * (k_max + 3)) / 2) | 1; }
+  // The costate sweep's look-ahead (WgCtx::costate_run) requests the coefficients of up to THREE stages below the first
+  // stage of its range (the tail of the chunk-parallel form: `post` = 5) and the output words of those stages; the
+  // values are never used, but the addresses must stay inside the workgroup's LDS allocation (an access outside it is
+  // an aperture violation on this platform).  Below the stage table sit `rows` row arrays of pitch Lp (+ `front` small
+  // words per instance in the lean plan): they must cover 3 stages of the table (3*NSTG words per instance, + the pair
+  // offset), and the arrays in front of the first `out` row must cover 3*NU words.  Built-in models (NSTG <= 6) pass
+  // from dv = 5 (lean) / any dv (full plans); a user model with many stage coefficients and a short horizon
+  // (NX = 4, NU = 1: NSTG = 24, Lp = dv|1) does not — it then runs on the lane mapping.
+  static bool lookahead_fits(int rows, int Lp, int front_words_per_inst) {
+    constexpr int NSTG = WgLds<M, T, 16>::NSTG;
+    return rows * Lp + front_words_per_inst >= 3 * NSTG + 2 && (rows - 1) * Lp + front_words_per_inst >= 3 * M::NU;
+  }
   // lean plan: 16 instances per workgroup in at most half a CU's LDS; the white-box hooks keep running on the full
   // (or fh_hbm) plan of the same sizes, so that one must fit as well
   static bool lean_supported(const cgmres_hip_config& c, size_t* bytes_out) {
     const int L = M::NU * c.dv;
     if (L > 320 || DxdtUsesP<M, T>::value) return false;  // (a state equation that reads p wants the horizon in LDS)
-    if (c.dv < 5) return false;  // (the costate look-ahead below the stage table must land in the row array before it)
     const int Lp = L | 1, Pp = (M::NP * (c.dv + 1)) | 1, Hp = pitch_H(c.k_max);
+    if (!lookahead_fits(1, Lp, 4 * M::NX + M::NU)) return false;  // (lean: W is the only row array, see WgLds)
     const size_t bl = WgLds<M, T, 16>::bytes(c.dv, c.k_max, Lp, Pp, Hp, PLAN_LEAN);
     int ipw_full;
     size_t b_full;
@@ -80,21 +92,21 @@ struct CtxWg final : cgmres_hip_ctx {
     const size_t b16h = WgLds<M, T, 16>::bytes(c.dv, c.k_max, Lp, Pp, Hp, PLAN_FH_HBM);
     const size_t b8 = WgLds<M, T, 8>::bytes(c.dv, c.k_max, Lp, Pp, Hp);
     if (fh_hbm_out) *fh_hbm_out = 0;
-    const char* force = getenv("CGMRES_HIP_IPW");  // measurement switch: "8" = 8 instances per workgroup where that fits
-    if (force && force[0] == '8' && b8 <= kLdsLimit) {
+    const bool full_ok = lookahead_fits(3, Lp, 0), fh_ok = lookahead_fits(2, Lp, 0);  // row arrays in front of the table
+    if ((c.flags & CGMRES_HIP_FLAG_IPW8) && b8 <= kLdsLimit && full_ok) {
       *ipw_out = 8, *bytes_out = b8;
       return true;
     }
-    if (b16 <= kLdsLimit) {
+    if (b16 <= kLdsLimit && full_ok) {
       *ipw_out = 16, *bytes_out = b16;
       return true;
     }
-    if (L > 160 && b16h <= kLdsLimit) {  // the long-vector kernels (MAXM = 20) are the ones that carry this mode
+    if (L > 160 && b16h <= kLdsLimit && fh_ok) {  // the long-vector kernels (MAXM = 20) are the ones that carry this mode
       *ipw_out = 16, *bytes_out = b16h;
       if (fh_hbm_out) *fh_hbm_out = 1;
       return true;
     }
-    if (b8 <= kLdsLimit) {
+    if (b8 <= kLdsLimit && full_ok) {
       *ipw_out = 8, *bytes_out = b8;
       return true;
     }
@@ -123,10 +135,6 @@ struct CtxWg final : cgmres_hip_ctx {
     } else if (cfg.variant == 0 && lean_ok && (cfg.batch + 15) / 16 > cus) {
       lean = true;
     }
-    if (const char* e = getenv("CGMRES_HIP_WG_PLAN")) {  // A/B switch for measurements: "lean" / "full"
-      if (!strcmp(e, "lean") && lean_ok) lean = true;
-      if (!strcmp(e, "full")) lean = false;
-    }
     if (lean) plan = PLAN_LEAN, fh_hbm = 0, lds_bytes = lean_bytes;
     else plan = fh_hbm ? PLAN_FH_HBM : PLAN_FULL;
     cfg.variant = lean ? 3 : 2;
@@ -136,9 +144,8 @@ struct CtxWg final : cgmres_hip_ctx {
     // its scratch fits as well (the white-box hooks keep the serial sweep)
     bool par = false;
     if (kParCostate<10> && want == 16 && !big && !lean && cfg.dv >= 4) {
-      const char* e = getenv("CGMRES_HIP_COSTATE");  // A/B switch for measurements: "serial"
       const size_t extra = WgLds<M, T, 16>::scan_count(cfg.dv) * sizeof(T) + 16;
-      if (lds_bytes + extra <= kLdsLimit && !(e && !strcmp(e, "serial"))) par = true, lds_bytes += extra;
+      if (lds_bytes + extra <= kLdsLimit && !(cfg.flags & CGMRES_HIP_FLAG_SERIAL_COSTATE)) par = true, lds_bytes += extra;
     }
     par_costate = par;
     if (want == 16 && !big) pick<16, 10>(lean, par);

@@ -352,11 +352,10 @@ struct PendulumDev {
   // Stage-table writes (all lanes, no branch), NSLOT = 6 slots per (stage, instance): x0, x1, x2 -> slots 0, 1, 2,
   // sin d, cos d, cos x1 -> slots 3, 4, 5.  x3 is not stored: stage_coeffs does not use x[3] because q3 = 0.  Per stage
   // ONE 8-byte store carries four useful values: the d-lanes their sin d / cos d, the cos-x1 lane its value, and the
-  // sin-x1 lane — whose own value no later phase reads — x1 instead (WgCtx::sweep_state, MERGE_X1: one select instead of
-  // a second LDS store, which costs the issuing wave 14.6 cycles).  Without MERGE_X1 the two values nobody needs (the
-  // d-lanes' -x1 and sin x1) go to slots 1 and 3 of the NEXT stage, where the proper lanes overwrite them one stage
-  // later (LDS operations of a wave complete in order); the table therefore has one pad stage after the last one
-  // (TAB_PAD).  x0 and x2 (the same value in every lane) are written by all lanes, every other stage (see x02_step).
+  // sin-x1 lane — whose own value no later phase reads — x1 instead (WgCtx::sweep_state: one select instead of a
+  // second LDS store, which costs the issuing wave 14.6 cycles).  x0 and x2 (the same value in every lane) are
+  // written by all lanes, every other stage (see x02_step).  TAB_PAD: one spare stage behind the table (an earlier
+  // store scheme parked unused values there; the LDS carve-up behind the table was tuned with it in place).
   static constexpr bool HAS_QUAD_SWEEP = true;
   static constexpr int NSLOT = 6, TRIG_SLOT0 = 3, TAB_PAD = 1;
   // x0 and x2 obey a recurrence of their own — x0' = x0 + dtau x2, x2' = x2 + dtau (-As x2 + Bs u0) (model.hpp:38,40) —
@@ -369,7 +368,7 @@ struct PendulumDev {
     x0 = fma_t(dtau, x2, x0);
     x2 = fma_t(dtau, f2, x2);
   }
-  static_assert(NBW <= NSLOT, "the junk redirection assumes the stage pitch is NSLOT");
+  static_assert(NBW <= NSLOT, "the coefficients of a stage overwrite its state/trig slots in place");
   static constexpr int QSLOT_XA = 0, QSLOT_XB = 2, QLANE_TRUE_X = 2;  // write2 slots; a lane whose x[1] is +x1
   struct QuadLane {
     static constexpr int NK = Math::NK;
@@ -380,7 +379,7 @@ struct PendulumDev {
     static constexpr int NRS = Math::NRS, NRC = Math::NRC;
     T rs[NRS], rs1, rc[NRC];       // rotation step: sgn*sin d = d (rs1 + z (rs[0] + ...)), cos d - 1 = z (rc[0] + ...)
     bool is_cos;
-    int slot_x1, slot_v;
+    int slot_v;
     template <class MC>
     __device__ __forceinline__ void init(int rho, const MC& mc) {
       is_cos = rho & 1;
@@ -398,8 +397,7 @@ struct PendulumDev {
 #pragma unroll
       for (int i = 0; i < NRC; ++i)
         if constexpr (!MC::OUTLINE) asm volatile("" : "+v"(rc[i]));  // kept in registers like the kernel constants
-      slot_x1 = rho < 2 ? NSLOT + 1 : 1;                                                  // d-lanes: junk, next stage
-      slot_v = rho == 0 ? 3 : (rho == 1 ? 4 : (rho == 2 ? NSLOT + 3 : 5));  // sin x1: junk, next stage
+      slot_v = rho == 0 ? 3 : (rho == 1 ? 4 : (rho == 2 ? 1 : 5));  // (the sin-x1 lane stores x1 in slot 1 instead)
     }
   };
   // this lane's trig value of `arg`; *amax accumulates max|arg| (arguments outside the fast range make the caller

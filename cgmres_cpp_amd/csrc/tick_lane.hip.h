@@ -176,6 +176,23 @@ template <class T>
 __device__ __forceinline__ T abs_t(T a) {
   return a < T(0) ? -a : a;
 }
+// neither NaN nor +-Inf (one v_cmp_class on the hardware)
+__device__ __forceinline__ bool finite_t(double a) { return __builtin_isfinite(a); }
+__device__ __forceinline__ bool finite_t(float a) { return __builtin_isfinite(a); }
+template <class T>
+__device__ __forceinline__ T quiet_nan();
+template <>
+__device__ __forceinline__ double quiet_nan<double>() { return __builtin_nan(""); }
+template <>
+__device__ __forceinline__ float quiet_nan<float>() { return __builtin_nanf(""); }
+// CGMRES_HIP_EXIT_NONFINITE: a non-finite residual / Arnoldi norm.  The reference tests for neither; every comparison
+// with a NaN is false there, the remaining iterations run on NaNs and the solution vector ends up NaN (include/gmres.hpp:
+// 39-41, 63-65, 93-95 all fall through).  Here the instance stops at once and its solution vector is set to NaN.
+template <class T>
+__device__ __forceinline__ int poison_nonfinite(T* x, int L, size_t ld) {
+  for (int e = 0; e < L; ++e) x[size_t(e) * ld] = quiet_nan<T>();
+  return 4;
+}
 
 // Gmres::gmres — gmres.hpp:28-112, per lane, sequential reductions in index order.
 // Returns the exit reason; n_ax = Arnoldi mat-vecs executed inside the k loop.
@@ -195,6 +212,7 @@ __device__ __forceinline__ int gmres_lane(const TickParams<T>& P, size_t ld, con
   }
   const T rho0 = sqrt_t<T>(ss);
   A.rho[0] = rho0;
+  if (!finite_t(rho0)) return poison_nonfinite(x, L, ld);  // (no such test in the reference: NaNs propagate there)
   if (rho0 < P.tol) return 2;  // gmres.hpp:39-41
   {
     const T inv = T(1.0) / rho0;  // gmres.hpp:44 via matrix.hpp:122-128
@@ -217,6 +235,7 @@ __device__ __forceinline__ int gmres_lane(const TickParams<T>& P, size_t ld, con
     for (int e = 0; e < L; ++e) nn += w[size_t(e) * ld] * w[size_t(e) * ld];
     const T hn = sqrt_t<T>(nn);  // :60
     Hk[size_t(k + 1) * ld] = hn;
+    if (!finite_t(hn)) return poison_nonfinite(x, L, ld);
     if (abs_t(hn) < T(DBL_EPSILON)) return 3;  // :63-65
     {
       const T inv = T(1.0) / hn;  // :67

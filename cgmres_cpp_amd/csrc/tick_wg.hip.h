@@ -167,7 +167,7 @@ struct WgLds {
     T* q = reinterpret_cast<T*>(base);
     const int k1 = P.kmax + 1;
     const bool lean = plan == PLAN_LEAN;
-    // The costate sweep's look-ahead reads up to two stages BELOW the start of its operand arrays (values never used):
+    // The costate sweep's look-ahead reads up to three stages BELOW the start of its operand arrays (values never used):
     // below the stage table that is a row array, below the first row of `out` it is whatever precedes the row arrays.
     // In the full plans U / Fh precede W; in the lean plan W would be the first array of the allocation, so the small
     // per-instance state arrays are placed in front of it (an access below the allocation is an aperture violation).
@@ -210,10 +210,7 @@ struct WgCtx {
   // lean plan: this row's U in the row layout for the whole launch — in registers, unless a row is 160 bytes per lane or
   // more (fp64 with MAXM = 20): those kernels are register-starved at 256 registers per wave and re-read their U row
   // from HBM/L2 where they need it (once per Arnoldi iteration, ~1/30 of the iteration's traffic)
-#ifndef CGM_AB_UREG_BYTES
-#define CGM_AB_UREG_BYTES 160
-#endif
-  static constexpr bool U_IN_REGS = LEAN && sizeof(T) * MAXM < CGM_AB_UREG_BYTES;
+  static constexpr bool U_IN_REGS = LEAN && sizeof(T) * MAXM < 160;
   static constexpr bool VK_IN_REGS = !LEAN || U_IN_REGS;  // v_k kept in registers between its creation and the next MGS
   T ureg[U_IN_REGS ? MAXM : 1];
   T* pTw;                   // lean plan: this workgroup's transposed parameter horizon [(stage*NP + j)*IPW + i]
@@ -474,15 +471,10 @@ struct WgCtx {
       // pointer advances by the same constant so the second stage of a trip addresses with immediates.
       // table/control pointers and the prefetched u0 persist across chunks (only the slow redo rewinds them)
       T* pa = tab + qi;
-#ifndef CGM_AB_MERGE_X1
-#define CGM_AB_MERGE_X1 1
-#endif
-      // MERGE_X1: the lane that holds +x1 stores it in the place of its own trig value (sin x1, which no later phase
-      // reads): one select (2 instructions) instead of a second 8-byte LDS store (14.6 cycles) per stage
-      constexpr bool MERGE_X1 = CGM_AB_MERGE_X1 != 0;
+      // the lane that holds +x1 stores it in the place of its own trig value (sin x1, which no later phase reads): one
+      // select (2 instructions) instead of a second 8-byte LDS store (14.6 cycles) per stage
       const bool x1_lane = rho == M::QLANE_TRUE_X;
-      T* pb = pa + Q.slot_x1 * IPW;
-      T* pv = pa + (MERGE_X1 && x1_lane ? 1 : Q.slot_v) * IPW;
+      T* pv = pa + Q.slot_v * IPW;
       const T* pu = U;
       T ua = T(0);
       if (goq) ua = pu[0];
@@ -490,10 +482,6 @@ struct WgCtx {
       // per stage (fast kernel), 2 = fresh evaluation with the library sin/cos.  A chunk starts in mode 0 from a fresh
       // value and is redone in mode 1 when an angle increment left the rotation's range, in mode 2 when an argument left
       // the fast kernel's range.
-#ifndef CGM_AB_ROT
-#define CGM_AB_ROT 1
-#endif
-      constexpr bool USE_ROT = CGM_AB_ROT != 0;
       T argp = T(0);
       int zmax = 0;
       bool rot_ok = true;  // wave-uniform, per sweep: cleared by the first redo
@@ -504,22 +492,14 @@ struct WgCtx {
             pa[o * STEP + M::QSLOT_XA * IPW] = x[0];
             pa[o * STEP + M::QSLOT_XB * IPW] = x[2];
           }
-          if constexpr (MERGE_X1) {
-            pv[o * STEP] = x1_lane ? x[1] : v;
-          } else {
-            pb[o * STEP] = x[1];
-            pv[o * STEP] = v;
-          }
+          pv[o * STEP] = x1_lane ? x[1] : v;
           if constexpr (MODE == 0)
             M::quad_stage_rot(x, v, argp, u0, dtau, dtau1, Q, mc, &zmax);
           else
             M::template quad_stage<MODE == 2>(x, v, u0, dtau, dtau1, Q, mc, &amax);
         };
         int k = 0;
-#ifndef CGM_AB_UNROLL4
-#define CGM_AB_UNROLL4 1
-#endif
-        if constexpr (CGM_AB_UNROLL4 && MODE == 0) {  // rotation mode: four stages per trip (a taken branch costs ~30 cycles)
+        if constexpr (MODE == 0) {  // rotation mode: four stages per trip (a taken branch costs ~30 cycles)
           for (; k + 4 <= n; k += 4) {
             const T ub = pu[NU];
             stage(0, ua);
@@ -529,7 +509,7 @@ struct WgCtx {
             stage(2, uc);
             ua = pu[4 * NU];
             stage(3, ud);
-            pa += 4 * STEP, pb += 4 * STEP, pv += 4 * STEP, pu += 4 * NU;
+            pa += 4 * STEP, pv += 4 * STEP, pu += 4 * NU;
           }
         }
         for (; k + 2 <= n; k += 2) {
@@ -537,11 +517,11 @@ struct WgCtx {
           stage(0, ua);
           ua = pu[2 * NU];
           stage(1, ub);
-          pa += 2 * STEP, pb += 2 * STEP, pv += 2 * STEP, pu += 2 * NU;
+          pa += 2 * STEP, pv += 2 * STEP, pu += 2 * NU;
         }
         if (k < n) {  // odd tail: only the last chunk can have one (chunk_len() is even)
           stage(0, ua);
-          pa += STEP, pb += STEP, pv += STEP, pu += NU;
+          pa += STEP, pv += STEP, pu += NU;
         }
       };
       for (int s0 = 0; s0 < dv; s0 += CH) {
@@ -553,12 +533,12 @@ struct WgCtx {
           auto rewind = [&]() {
 #pragma unroll
             for (int c = 0; c < NX; ++c) x[c] = xs[c];
-            pa = tab + qi + s0 * STEP, pb = pa + Q.slot_x1 * IPW, pv = pa + (MERGE_X1 && x1_lane ? 1 : Q.slot_v) * IPW;
+            pa = tab + qi + s0 * STEP, pv = pa + Q.slot_v * IPW;
             pu = U + s0 * NU;
             ua = pu[0];
           };
-          bool fresh = !USE_ROT || !rot_ok;  // wave-uniform: run this chunk with a fresh evaluation per stage
-          if (USE_ROT && rot_ok) {
+          bool fresh = !rot_ok;  // wave-uniform: run this chunk with a fresh evaluation per stage
+          if (rot_ok) {
             // the chunk starts from a fresh value (the sweep's first one comes from quad_begin)
             if (s0 > 0) v = M::template quad_trig<false>(M::quad_arg(x, Q), Q, mc, &amax);
             argp = M::quad_arg(x, Q);
@@ -657,11 +637,8 @@ struct WgCtx {
   // barrier that releases the chunk): an item-by-item fetch exposes two dependent HBM/L2 round trips per item and
   // the coefficient waves then fall behind the sweep wave (measured: +20 % on every sweep).
   static constexpr bool HBM_OPERANDS = LEAN || MAXM > 10;  // kernels that carry the fh_hbm / lean code
-#ifndef CGM_AB_ALT_X02
-#define CGM_AB_ALT_X02 1
-#endif
   // the pipelined quad sweep stores x0 / x2 every other stage; the coefficient phase works on stage pairs
-  static constexpr bool ALT_X02 = CGM_AB_ALT_X02 && M::HAS_QUAD_SWEEP && IPW * 16 >= 128;
+  static constexpr bool ALT_X02 = M::HAS_QUAD_SWEEP && IPW * 16 >= 128;
   static constexpr int COEFF_GROUP = sizeof(T) == 8 ? 2 : 3;
   struct CoeffPre {
     T p[M::NP > 0 ? M::NP : 1], fh[M::NU];
@@ -899,11 +876,12 @@ struct WgCtx {
     // Three register sets, three stages per trip: the operands of stage t-2 are requested while stage t computes
     // (two LDS latencies of slack).  q/o sit on stage s-4 of the trip that starts with stage s: every access is
     // pointer + non-negative immediate.  Below stage 0 the look-ahead reads words of the preceding LDS arrays
-    // (at most 2 stages = 2*STEP scalars, less than one row array), never used.  LDS accesses outside the
-    // workgroup's allocation FAULT on this platform (aperture violation): -DCGM_DEBUG_LDS checks every address here.
+    // (at most 3 stages = 3*STEP scalars — the `post` tail below — which CtxWg::lookahead_fits guarantees to lie
+    // inside the row arrays in front of the table), never used.  LDS accesses outside the workgroup's allocation
+    // FAULT on this platform (aperture violation): -DCGM_DEBUG_LDS checks every address here.
 #ifdef CGM_DEBUG_LDS
     auto chk = [&](const void* ptr, int what) {
-      const long off = static_cast<const char*>(ptr) - reinterpret_cast<const char*>(S.U);
+      const long off = static_cast<const char*>(ptr) - reinterpret_cast<const char*>(LEAN ? S.xs : S.U);
       if (off < 0 || off + 16 > long(P.lds_bytes)) printf("LDS OOB what=%d off=%ld tid=%d dv=%d\n", what, off, tid, P.dv);
     };
 #else
@@ -1305,9 +1283,6 @@ struct WgCtx {
     // Ring of NBUF register buffers for the older basis vectors: NBUF rows are requested before the sweep starts, and
     // every buffer is refilled with row i+NBUF as soon as round i has consumed it, so each load has NBUF-1 rounds
     // (~1000 cycles) to arrive.  Static buffer indices: one fully unrolled instance per iteration count (<= KRING).
-#ifndef CGM_AB_NBUF
-#define CGM_AB_NBUF 3
-#endif
 #define CGM_KCASE(f, n) \
   case n:               \
     f(std::integral_constant<int, n>{}); \
@@ -1315,7 +1290,7 @@ struct WgCtx {
 #define CGM_KCASES(f) \
   CGM_KCASE(f, 1) CGM_KCASE(f, 2) CGM_KCASE(f, 3) CGM_KCASE(f, 4) CGM_KCASE(f, 5) CGM_KCASE(f, 6) CGM_KCASE(f, 7) \
   CGM_KCASE(f, 8) CGM_KCASE(f, 9) CGM_KCASE(f, 10) CGM_KCASE(f, 11) CGM_KCASE(f, 12)
-    constexpr int NBUF = MAXM <= 10 ? CGM_AB_NBUF : 2, KRING = 12;
+    constexpr int NBUF = MAXM <= 10 ? 3 : 2, KRING = 12;
     // workgroup-uniform; longer bases use the plain streaming loop.  So does the lean plan: with 256 registers per wave the
     // twelve straight-line copies of the rounds push everything that lives across them (U, the sweep constants) into
     // scratch — in every block of the kernel, executed or not.
@@ -1325,10 +1300,7 @@ struct WgCtx {
     // push the Gram-Schmidt rounds into AGPR copies and scratch (profiles/r02_isa_summary.md).  Park it in HBM
     // (own row, same thread writes and reads it back: program order) and fetch it back behind the back substitution.
     T* const park_row = P.park + size_t(blockIdx.x * IPW + inst) * P.Lv;
-#ifndef CGM_AB_PARK
-#define CGM_AB_PARK 1
-#endif
-    constexpr bool PARK = (MAXM > 10 || (LEAN && sizeof(T) == 8)) && CGM_AB_PARK;  // (lean fp64: 256 registers per wave)
+    constexpr bool PARK = MAXM > 10 || (LEAN && sizeof(T) == 8);  // (lean fp64: 256 registers per wave)
     if constexpr (PARK) store_vec(park_row, xv);
     // r0 = b - A x0 ; rho = ||r0||      gmres.hpp:33-37
     {
@@ -1340,6 +1312,10 @@ struct WgCtx {
       }
       const T rho0 = sqrt_t<T>(row16_sum(ss));
       if (r == 0) rhoi[0] = rho0;
+      if (active && !finite_t(rho0)) {  // CGMRES_HIP_EXIT_NONFINITE (row-uniform; see poison_nonfinite in tick_lane.hip.h)
+        active = false;
+        if (r == 0) S.reason[inst] = 4;
+      }
       if (active && rho0 < P.tol) {  // gmres.hpp:39-41
         active = false;
         if (r == 0) S.reason[inst] = 2;
@@ -1358,10 +1334,7 @@ struct WgCtx {
     // path — 16 lanes of wave 1 (one per instance) do column k-1 while wave 0 runs the first chunk of sweep k, where
     // the coefficient waves would otherwise wait; the last column is done in place.  With tol > 0 the column decides
     // whether the next mat-vec runs at all (gmres.hpp:93-95) and stays where the reference has it.
-#ifndef CGM_AB_DEFER_HESS
-#define CGM_AB_DEFER_HESS 1
-#endif
-    const bool defer_hess = CGM_AB_DEFER_HESS && IPW * 16 >= 128 && P.tol == T(0);  // workgroup-uniform
+    const bool defer_hess = IPW * 16 >= 128 && P.tol == T(0);  // workgroup-uniform
     int k = 0;
     for (; k < kmax; ++k) {  // gmres.hpp:46
       CGM_STAMP(*this, 14);
@@ -1460,10 +1433,10 @@ struct WgCtx {
           Hk[k + 1] = hn;
           S.nax[inst] = k + 1;
         }
-        if (abs_t(hn) < T(DBL_EPSILON)) {  // :63-65 breakdown: x untouched
+        if (abs_t(hn) < T(DBL_EPSILON) || !finite_t(hn)) {  // :63-65 breakdown: x untouched; non-finite: x <- NaN below
           active = false;
           if (r == 0) {
-            S.reason[inst] = 3;
+            S.reason[inst] = finite_t(hn) ? 3 : 4;
             S.flag[inst] = 0;
           }
         } else {
@@ -1570,6 +1543,10 @@ struct WgCtx {
       }
 #pragma unroll
       for (int m = 0; m < MAXM; ++m) xv[m] = xv[m] + acc[m];
+    }
+    if (valid && reason == 4) {  // CGMRES_HIP_EXIT_NONFINITE: what the reference's fall-through ends with
+#pragma unroll
+      for (int m = 0; m < MAXM; ++m) xv[m] = elem(m) < P.L ? quiet_nan<T>() : T(0);
     }
   }
 

@@ -30,7 +30,9 @@
 extern "C" {
 #endif
 
-#define CGMRES_HIP_ABI_VERSION 1
+/* 2: cgmres_hip_config gained `flags`; plugin contract (the model plugin picks the mapping, closed loop with a reference
+ *    sequence); exit reason CGMRES_HIP_EXIT_NONFINITE.  A plugin or binding built against version 1 is rejected. */
+#define CGMRES_HIP_ABI_VERSION 2
 
 /* problem definitions compiled into the library (reference <example>/model.hpp) */
 enum {
@@ -56,7 +58,18 @@ enum {
   CGMRES_HIP_EXIT_NATURAL = 0,        /* all k_max Arnoldi iterations ran      gmres.hpp:46 */
   CGMRES_HIP_EXIT_CONVERGED = 1,      /* |rho_e[k+1]| < tol                     gmres.hpp:93-95 */
   CGMRES_HIP_EXIT_SMALL_RESIDUAL = 2, /* ||r0|| < tol, dUdt untouched           gmres.hpp:39-41 */
-  CGMRES_HIP_EXIT_BREAKDOWN = 3       /* |h(k+1,k)| < DBL_EPSILON, dUdt untouched  gmres.hpp:63-65 */
+  CGMRES_HIP_EXIT_BREAKDOWN = 3,      /* |h(k+1,k)| < DBL_EPSILON, dUdt untouched  gmres.hpp:63-65 */
+  /* ||r0|| or h(k+1,k) is NaN/Inf: the reference has no test for it — every comparison with a NaN is false, the solve
+   * runs on and NaNs propagate into dUdt, U and u.  Here the solve of that instance stops at the first
+   * non-finite norm, its dUdt is set to NaN (what the reference ends up with), and the status says why. */
+  CGMRES_HIP_EXIT_NONFINITE = 4
+};
+
+/* cgmres_hip_config.flags: choices inside a mapping that are normally the library's (measurement / A-B use) */
+enum {
+  CGMRES_HIP_FLAG_SERIAL_COSTATE = 1, /* wg mapping: keep the one-lane-per-instance costate sweep (no chunk-parallel scan) */
+  CGMRES_HIP_FLAG_IPW8 = 2,           /* wg mapping: 8 instead of 16 instances per workgroup where that fits */
+  CGMRES_HIP_FLAG_NO_BINNING = 4      /* closed loop: keep instances in caller order inside the workgroups (no k-binning) */
 };
 
 /* cgmres_hip_closed_loop_device advances up to this many consecutive ticks per kernel launch (the controller
@@ -76,6 +89,8 @@ typedef struct cgmres_hip_config {
   int32_t variant;     /* kernel mapping: 0 = library's choice, 1 = "lane", 2 = "wg" (one workgroup per CU: everything
                           of 16 instances in LDS), 3 = "wg-lean" (half the LDS, two workgroups per CU);
                           get_config returns the resolved value */
+  int32_t flags;       /* CGMRES_HIP_FLAG_* (0 = library defaults) */
+  int32_t reserved;    /* 0 */
   double tol;          /* Model::tol */
   double dt;           /* Model::dt   sampling period */
   double h;            /* Model::h    forward-difference step */
@@ -99,8 +114,9 @@ int cgmres_hip_model_probe(int32_t model_id, int32_t device, const double* x, co
 /* Registers a USER model: `plugin_path` is a shared object generated from a reference-style Model header
  * (static constexpr dim_x/.../tol and static dxdt/dPhidx/dHdx/dHdu/ddHduu, <example>/model.hpp:7-76) by
  * cgmres_cpp_amd/plugin.py (hipcc, gfx950).  *model_id receives an id >= CGMRES_HIP_MODEL_USER_BASE that every
- * other entry point accepts; such models run on the "lane" mapping in fp64.  Registering the same path twice
- * returns the same id.  This is what a `Cgmres<Model>` facade binds for a Model that is not in the registry. */
+ * other entry point accepts; such models run in fp64, on the "wg" mapping when their sizes fit its LDS plan
+ * (the affine costate split is generated from the user's own dHdx / dHdu, csrc/user_model.hip.h) and on the "lane"
+ * mapping otherwise.  Registering the same path twice returns the same id.  This is what a `Cgmres<Model>` facade binds for a Model that is not in the registry. */
 int cgmres_hip_register_model(const char* plugin_path, int32_t* model_id);
 /* Diagnostic: the device sin/cos the horizon sweeps use (fp64), evaluated at n host-supplied arguments. */
 int cgmres_hip_selftest_sincos(int32_t device, const double* a, int32_t n, double* s, double* c);

@@ -46,9 +46,11 @@ def test_registry_without_gpu(lib):
 
 
 def test_config_struct_layout():
-    # int32 x8, double x6, pointer: the C struct of include/cgmres_hip.h
-    assert ctypes.sizeof(cg.Config) == 8 * 4 + 6 * 8 + 8
-    assert cg.Config.tol.offset == 32 and cg.Config.stream.offset == 80
+    # int32 x10 (ABI 2: + flags, reserved), double x6, pointer: the C struct of include/cgmres_hip.h
+    assert ctypes.sizeof(cg.Config) == 10 * 4 + 6 * 8 + 8
+    assert cg.Config.flags.offset == 32 and cg.Config.tol.offset == 40 and cg.Config.stream.offset == 88
+    hdr = open(os.path.join(ROOT, "include", "cgmres_hip.h")).read()
+    assert f"#define CGMRES_HIP_ABI_VERSION {cg.ABI_VERSION}" in hdr
 
 
 def test_argument_validation_and_no_cpu_fallback(lib):

@@ -241,14 +241,12 @@ def test_seeded_batch_vs_oracle(orc, model, dv, kmax, tol, B, ticks, variant):
 ])
 def test_chunk_parallel_costate_vs_serial_and_oracle(orc, model, dv, kmax, tol, B, monkeypatch):
     """The chunk-parallel costate sweep (full plan, short vectors) against the oracle AND against the
-    serial sweep of the same library (CGMRES_HIP_COSTATE=serial picks the other kernel instantiation) at horizon
+    serial sweep of the same library (flags=FLAG_SERIAL_COSTATE picks the other kernel instantiation) at horizon
     lengths around the chunking's edge cases.  Teacher-forced ticks, early exits included (tol > 0)."""
     x0, u0, p = orc.batch_scenario(model, B)
     refs = _oracle_batch(orc, model, dv, kmax, tol, x0, u0, p)
-    monkeypatch.delenv("CGMRES_HIP_COSTATE", raising=False)
     par = cg.CgmresBatch(model, batch=B, dv=dv, k_max=kmax, tol=tol, variant=2)
-    monkeypatch.setenv("CGMRES_HIP_COSTATE", "serial")
-    ser = cg.CgmresBatch(model, batch=B, dv=dv, k_max=kmax, tol=tol, variant=2)
+    ser = cg.CgmresBatch(model, batch=B, dv=dv, k_max=kmax, tol=tol, variant=2, flags=cg.FLAG_SERIAL_COSTATE)
     assert par.variant_name == "wg+parallel-costate" and ser.variant_name == "wg"  # (the sizes above fit its LDS scratch)
     for c in (par, ser):
         c.set_ptau_repeat(p)
@@ -495,6 +493,41 @@ def test_status_exit_paths(orc, variant):
     assert np.all(reason == cg.EXIT_BREAKDOWN) and np.all(n_ax == 1)
     assert np.array_equal(d0, d1) and np.array_equal(d1, np.zeros_like(d1))
     assert np.array_equal(U1, U0)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_nonfinite_state_is_flagged_per_instance(orc, variant):
+    """CGMRES_HIP_EXIT_NONFINITE: a NaN / Inf plant state makes ||r0|| non-finite.  The reference has no test for it —
+    every comparison with a NaN is false (gmres.hpp:39-41, 63-65, 93-95 fall through) and NaNs end up in dUdt, U and u;
+    the device ends with the same NaNs, stops that instance at once and SAYS so in the status.  The other instances of
+    the same workgroup are untouched (instances never exchange data)."""
+    model, dv, km, B = 0, 50, 10, 40
+    x0, u0, p = orc.batch_scenario(model, B)
+    bad = {3: np.nan, 20: np.inf, 37: -np.inf}
+    x = x0.copy()
+    for i, v in bad.items():
+        x[i, i % 2] = v
+    c = cg.CgmresBatch(model, batch=B, dv=dv, k_max=km, tol=1e-6, variant=variant)
+    c.set_ptau_repeat(p)
+    c.init_u0(u0)
+    c.init_u0_newton(u0, x0, p, 10)
+    for tick in range(2):
+        u = c.control(x)
+        n_ax, reason = c.get_status()
+        _, U, d = c.get_state()
+        for i in range(B):
+            r = orc.Controller(model, dv, km, 1e-6)
+            orc.start_controller(r, x0[i], u0[i], p[i])
+            for _ in range(tick + 1):
+                ur = r.control(x[i])
+            if i in bad:
+                assert reason[i] == cg.EXIT_NONFINITE and n_ax[i] == 0, (tick, i, reason[i], n_ax[i])
+                assert np.all(np.isnan(ur))                       # the reference's fall-through: NaN everywhere
+                assert np.all(np.isnan(d[i])) and np.all(np.isnan(U[i])) and np.all(np.isnan(u[i]))
+            else:
+                assert reason[i] == r.last_solve()[2] and n_ax[i] == r.last_solve()[0], (tick, i)
+                assert np.max(np.abs(u[i] - ur)) <= U_TOL, (tick, i)
+    c.close()
 
 
 @pytest.mark.parametrize("variant", VARIANTS)

@@ -36,12 +36,11 @@ else:
     for rnd in range(3):
         for n in names:
             env = dict(os.environ)
-            lib, _, sw = n.partition("@")  # name@serial: CGMRES_HIP_COSTATE=serial
-            if sw:
-                env["CGMRES_HIP_COSTATE"] = sw
+            lib, _, sw = n.partition("@")  # name@serial: bench.py --flags 1 (CGMRES_HIP_FLAG_SERIAL_COSTATE)
+            extra = ["--flags", "1"] if sw == "serial" else []
             if lib != "base":
                 env["CGMRES_HIP_LIB"] = os.path.join(AB, lib, "lib.so")
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-ref-mode", "--steps", "150", "--warmup", "30"] + os.environ.get("AB_BENCH_ARGS", "").split(),
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-ref-mode", "--steps", "150", "--warmup", "30"] + extra + os.environ.get("AB_BENCH_ARGS", "").split(),
                                env=env, capture_output=True, text=True)
             res[n].append(json.loads(r.stdout.strip().split("\n")[-1])["ms_per_step"])
     for n in names:
