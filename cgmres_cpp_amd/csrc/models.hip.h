@@ -462,30 +462,53 @@ struct PendulumDev {
   static __device__ __forceinline__ void quad_stage_rot(T* x, T& v, T& argp, T u0, T dtau, T dtau1, const QuadLane& Q,
                                                         const MC& mc, int* zmax) {
     constexpr int NRS = QuadLane::NRS, NRC = QuadLane::NRC;
-    const T m = fma_t(fma_t(Q.mp, x[2], Q.mq), x[2], fma_t(Q.mr, u0, Q.ms));
-    const T trig_sum = quad_sum(mul2(m, v));
-    const T f3 = fma_t(C22, x[2] - x[3], trig_sum);
-    const T f2 = fma_t(-As, x[2], Bs * u0);
-    x[0] = fma_t(dtau, x[2], x[0]);
-    x[1] = fma_t(dtau1, x[3], x[1]);
-    x[2] = fma_t(dtau, f2, x[2]);
-    x[3] = fma_t(dtau, f3, x[3]);
-    const T arg = quad_arg(x, Q);
-    const T d = arg - argp;
-    argp = arg;
-    const T z = mul2(d, d);
+    static_assert(NRC == NRS + 1, "the two Taylor polynomials are advanced in lock-step");
+    // Two independent dependency chains per stage — A: weight, product, quad sum, f3 -> x3';  B: new angle, increment,
+    // the two Taylor polynomials, partner exchange -> v' — and on this hardware a fp64 operation that consumes the result
+    // of the instruction issued right before it costs an extra issue slot (the compiler pads with s_nop: 4 per stage
+    // when it schedules the chains one after the other, as it did for every second stage of the unrolled loop).
+    // The groups below alternate A and B; a sched_barrier between groups keeps the scheduler from re-serialising them.
+#define CGM_SB() __builtin_amdgcn_sched_barrier(0)
+    // (a barrier after EVERY statement: the order below is the schedule.  A DPP move must not follow the instruction
+    // that produces its source within two issue slots, a fp64 operation not its producer within one.)
+    const T ma = fma_t(Q.mp, x[2], Q.mq);           CGM_SB();  // A
+    const T x1n = fma_t(dtau1, x[3], x[1]);         CGM_SB();  // B  (old x3)
+    const T mb = fma_t(Q.mr, u0, Q.ms);             CGM_SB();  // A
+    const T x0n = fma_t(dtau, x[2], x[0]);          CGM_SB();  // B  (old x2)
+    const T m = fma_t(ma, x[2], mb);                CGM_SB();  // A
+    const T arg = fma_t(Q.kap, x0n, x1n);           CGM_SB();  // B
+    T t = mul2(m, v);                               CGM_SB();  // A  (mul2: the same rounded product in every lane of the quad)
+    const T d = arg - argp;                         CGM_SB();  // B
+    const T f2a = Bs * u0;                          CGM_SB();  // C
+    const T z = mul2(d, d);                         CGM_SB();  // B
+    T tp = dpp_move<DPP_QUAD_SWAP1>(t);             CGM_SB();  // A  (two slots after t)
+    T ps = fma3(z, Q.rs[NRS - 1], Q.rs[NRS - 2]);   CGM_SB();  // B
+    T pc = fma3(z, Q.rc[NRC - 1], Q.rc[NRC - 2]);   CGM_SB();  // B
+    t = t + tp;                                     CGM_SB();  // A
+#pragma unroll
+    for (int i = NRS - 3; i >= 0; --i) {            // B (fp64: one round)
+      ps = fma3(z, ps, Q.rs[i]);                    CGM_SB();
+      pc = fma3(z, pc, Q.rc[i + 1]);                CGM_SB();
+    }
+    const T f2 = fma_t(-As, x[2], f2a);             CGM_SB();  // C
+    tp = dpp_move<DPP_QUAD_SWAP2>(t);               CGM_SB();  // A
+    ps = fma3(z, ps, Q.rs1);                        CGM_SB();  // B
+    pc = fma3(z, pc, Q.rc[0]);                      CGM_SB();  // B
+    const T df = x[2] - x[3];                       CGM_SB();  // A
+    const T trig_sum = t + tp;                      CGM_SB();  // A  (bit-identical in the four lanes)
+    const T sd = mul2(d, ps);                       CGM_SB();  // B  +-sin d
+    const T pv = dpp_move<DPP_QUAD_SWAP1>(v);       CGM_SB();  // B
+    const T f3 = fma_t(C22, df, trig_sum);          CGM_SB();  // A
+    const T cm1 = mul2(z, pc);                      CGM_SB();  // B  cos d - 1
+    T w = mul2(pv, sd);                             CGM_SB();  // B
+    x[3] = fma_t(dtau, f3, x[3]);                   CGM_SB();  // A
+    x[2] = fma_t(dtau, f2, x[2]);                   CGM_SB();  // C
+    w = fma_t(v, cm1, w);                           CGM_SB();  // B
     const int zb = nonneg_bits(z);
-    *zmax = zb > *zmax ? zb : *zmax;
-    T ps = fma3(z, Q.rs[NRS - 1], Q.rs[NRS - 2]);
-#pragma unroll
-    for (int i = NRS - 3; i >= 0; --i) ps = fma3(z, ps, Q.rs[i]);
-    const T sd = mul2(d, fma3(z, ps, Q.rs1));  // +-sin d
-    T pc = fma3(z, Q.rc[NRC - 1], Q.rc[NRC - 2]);
-#pragma unroll
-    for (int i = NRC - 3; i >= 0; --i) pc = fma3(z, pc, Q.rc[i]);
-    const T cm1 = mul2(z, pc);                 // cos d - 1
-    const T pv = dpp_move<DPP_QUAD_SWAP1>(v);
-    v = v + fma_t(v, cm1, mul2(pv, sd));
+    *zmax = zb > *zmax ? zb : *zmax;                CGM_SB();
+    x[0] = x0n, x[1] = x1n, argp = arg;
+    v = v + w;                                      CGM_SB();  // B
+#undef CGM_SB
   }
   static __device__ __forceinline__ bool quad_rot_bad(int zmax) { return zmax > nonneg_bits(T(Math::rot_zmax)); }
   static __device__ __forceinline__ void ddHduu(T* m, const T*, const T* u, const T*, const T*) {  // :64-76

@@ -81,6 +81,11 @@ struct WgParams {
   T hook_dtau;
 };
 
+#ifdef CGM_DEBUG_LDS
+// Diagnostic build only: set by the costate sweep when one of its LDS addresses falls outside the workgroup's allocation
+// (0x10000 | what << 12 | thread); read back through cgmres_hip_plugin_debug_lds_oob (user_model.hip.h)
+__device__ int g_cgm_lds_oob;
+#endif
 // Diagnostic build only: accumulate shader-clock deltas per phase (thread 0 of block 0).  Compiles to nothing
 // in the product build.
 #ifdef CGM_STAMPS
@@ -880,9 +885,9 @@ struct WgCtx {
     // inside the row arrays in front of the table), never used.  LDS accesses outside the workgroup's allocation
     // FAULT on this platform (aperture violation): -DCGM_DEBUG_LDS checks every address here.
 #ifdef CGM_DEBUG_LDS
-    auto chk = [&](const void* ptr, int what) {
+    auto chk = [&](const void* ptr, int what) {  // (a flag, not a printf: 40 printf sites made this build take 20 minutes)
       const long off = static_cast<const char*>(ptr) - reinterpret_cast<const char*>(LEAN ? S.xs : S.U);
-      if (off < 0 || off + 16 > long(P.lds_bytes)) printf("LDS OOB what=%d off=%ld tid=%d dv=%d\n", what, off, tid, P.dv);
+      if (off < 0 || off + 16 > long(P.lds_bytes)) g_cgm_lds_oob = 0x10000 | (what << 12) | (tid & 0xfff);
     };
 #else
     auto chk = [&](const void*, int) {};

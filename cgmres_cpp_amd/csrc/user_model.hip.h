@@ -187,6 +187,16 @@ inline bool user_model_is_affine_in_costate(int device) {
 
 }  // namespace cgm
 
+#ifdef CGM_DEBUG_LDS
+// diagnostic plugin builds only: the out-of-allocation flag of the costate sweep (0 = every address was inside), cleared
+extern "C" int cgmres_hip_plugin_debug_lds_oob(void) {
+  int v = -1, zero = 0;
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(&v, HIP_SYMBOL(cgm::g_cgm_lds_oob), sizeof v) != hipSuccess) return -1;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(cgm::g_cgm_lds_oob), &zero, sizeof zero);
+  return v;
+}
+#endif
+
 // The four entry points of a model plugin (bound by cgmres_hip_register_model in capi.hip).
 #define CGMRES_HIP_DEFINE_PLUGIN(MODEL)                                                                          \
   extern "C" {                                                                                                   \

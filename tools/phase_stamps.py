@@ -17,6 +17,9 @@ def opt(name, default):
             return int(a.split("=")[1])
     return default
 lib = os.path.join(diag, f"libcgmres_hip_stamps_{MODEL}.so")
+for a in sys.argv:
+    if a.startswith("--lib="):  # a stamp build made earlier (e.g. an A/B pair copied aside)
+        lib = os.path.abspath(a[6:])
 if "--build" in sys.argv or "--build-only" in sys.argv or not os.path.exists(lib):
     srcs, _ = b.sources()
     from concurrent.futures import ThreadPoolExecutor
