@@ -35,26 +35,35 @@ struct CtxWg final : cgmres_hip_ctx {
   T *x_dev = nullptr, *u_dev = nullptr;
   int fh_hbm_for_hooks = 0;
 
-  bool par_costate = false;
-  const char* variant_name() const override { return plan == PLAN_LEAN ? "wg-lean" : (par_costate ? "wg+parallel-costate" : "wg"); }
+  int par_costate = 0;  // 0 serial, 1 chunk-parallel with LDS scratch, 2 two-pass (WgCtx::PAR)
+  const char* variant_name() const override {
+    static const char* const names[2][3] = {{"wg", "wg+parallel-costate", "wg+two-pass-costate"},
+                                            {"wg-lean", "wg-lean", "wg-lean+two-pass-costate"}};
+    return names[plan == PLAN_LEAN][par_costate];
+  }
 
   // (IPW, MAXM) instantiations: 16 or 8 instances per workgroup, vectors up to 160 or 320 elements; the lean LDS plan
   // (two workgroups per CU) exists for 16 instances per workgroup
   template <int IPW, int MAXM>
-  void pick(bool lean, bool par) {
+  void pick(bool lean, int par) {
     k_tick = tick_wg_kernel<M, T, IPW, MAXM>;
     if constexpr (IPW == 16) {
       if (lean) k_tick = tick_wg_kernel<M, T, IPW, MAXM, true>;
       if constexpr (kParCostate<MAXM>) {
-        if (par && !lean) k_tick = tick_wg_kernel<M, T, IPW, MAXM, false, true>;
+        if (par == 1 && !lean) k_tick = tick_wg_kernel<M, T, IPW, MAXM, false, 1>;
+      }
+      if constexpr (kPar2) {
+        if (par == 2) k_tick = lean ? tick_wg_kernel<M, T, IPW, MAXM, true, 2> : tick_wg_kernel<M, T, IPW, MAXM, false, 2>;
       }
     }
     k_hook = hook_wg_kernel<M, T, IPW, MAXM>;
     ipw = IPW, maxm = MAXM;
   }
-  // kernels with the chunk-parallel costate sweep (WgCtx::sweep_costate_par) exist for the short-vector instantiations
+  // kernels with the chunk-parallel costate sweep: the form with per-stage LDS scratch (WgCtx::sweep_costate_par) exists for
+  // the short-vector instantiations, the two-pass form (sweep_costate_2pass) for every 16-instance kernel
+  static constexpr bool kPar2 = M::COSTATE_HOM && M::NX * 16 <= 64 && M::NX % 2 == 0;
   template <int MAXM>
-  static constexpr bool kParCostate = M::COSTATE_HOM && MAXM == 10 && M::NX * 16 <= 64 && M::NX % 2 == 0;
+  static constexpr bool kParCostate = kPar2 && MAXM == 10;
   static int pitch_H(int k_max) { return ((k_max * (k_max + 3)) / 2) | 1; }
   // The costate sweep's look-ahead (WgCtx::costate_run) requests the coefficients of up to THREE stages below the first
   // stage of its range (the tail of the chunk-parallel form: `post` = 5) and the output words of those stages; the
@@ -142,16 +151,25 @@ struct CtxWg final : cgmres_hip_ctx {
     const bool big = L > 160;
     // chunk-parallel costate sweep (WgCtx::sweep_costate_par): its own kernel instantiation on the full plan, taken when
     // its scratch fits as well (the white-box hooks keep the serial sweep)
-    bool par = false;
-    if (kParCostate<10> && want == 16 && !big && !lean && cfg.dv >= 4) {
+    int par = 0;
+    const bool serial = cfg.flags & CGMRES_HIP_FLAG_SERIAL_COSTATE, two_pass = cfg.flags & CGMRES_HIP_FLAG_TWO_PASS_COSTATE;
+    if (kParCostate<10> && want == 16 && !big && !lean && cfg.dv >= 4 && !serial && !two_pass) {
       const size_t extra = WgLds<M, T, 16>::scan_count(cfg.dv) * sizeof(T) + 16;
-      if (lds_bytes + extra <= kLdsLimit && !(cfg.flags & CGMRES_HIP_FLAG_SERIAL_COSTATE)) par = true, lds_bytes += extra;
+      if (lds_bytes + extra <= kLdsLimit) par = 1, lds_bytes += extra;
+    }
+    if (kPar2 && want == 16 && par == 0 && !serial) {
+      // two-pass form: 4 chunks where their boundary records fit behind the plan's arrays, 3 otherwise (the lean plans)
+      const size_t limit = lean ? kLdsLimitLean : kLdsLimit;
+      for (int chunks = 4; chunks >= 3 && par == 0; --chunks) {
+        const size_t extra = WgLds<M, T, 16>::scan2_count(chunks) * sizeof(T) + 16;
+        if (cfg.dv >= 2 * chunks && lds_bytes + extra <= limit) par = 2, lds_bytes += extra, P.cs_chunks = chunks;
+      }
     }
     par_costate = par;
     if (want == 16 && !big) pick<16, 10>(lean, par);
-    if (want == 16 && big) pick<16, 20>(lean, false);
-    if (want == 8 && !big) pick<8, 10>(false, false);
-    if (want == 8 && big) pick<8, 20>(false, false);
+    if (want == 16 && big) pick<16, 20>(lean, par);
+    if (want == 8 && !big) pick<8, 10>(false, 0);
+    if (want == 8 && big) pick<8, 20>(false, 0);
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 int(lds_bytes)));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hook), hipFuncAttributeMaxDynamicSharedMemorySize,

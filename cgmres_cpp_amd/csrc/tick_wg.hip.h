@@ -51,6 +51,7 @@ enum WgMode { WG_TICK = 0, WG_HOOK_F = 1, WG_HOOK_PREPARE = 2, WG_HOOK_AX = 3, W
 template <class T>
 struct WgParams {
   int B, dv, kmax, L, Lp, Lg, Lv, Pp, Hp, fh_hbm, lds_bytes;  // fh_hbm: F(U,x+hf,t+h) is kept in HBM only (P.Fh), see WgLds
+  int cs_chunks;  // chunks of the two-pass costate sweep (WgCtx::sweep_costate_2pass): 3 or 4, what the LDS budget allows
    // Lp/Pp/Hp: odd LDS row pitches (Hp: the COMPACT Hessenberg, column k = k+2 entries at offset k(k+3)/2);
    // Lg: global row pitch (multiple of 16); Lv = 16*MAXM: pitch of the Krylov rows (pads kept zero, no guards)
   T h, dt, tol, inv_h, one_m_zh, dtau_h, dtau_0;
@@ -165,8 +166,14 @@ struct WgLds {
   static __host__ __device__ size_t scan_count(int dv) {
     return size_t(3 * (dv >> 2)) * M::NUL * M::NX * IPW + size_t(4) * IPW * SCAN_REC;
   }
-  static __host__ __device__ size_t bytes(int dv, int kmax, int Lp, int Pp, int Hp, int plan = PLAN_FULL, bool par = false) {
-    return count_T(dv, kmax, Lp, Pp, Hp, plan) * sizeof(T) + 4 * IPW * sizeof(int) + 16 + (par ? scan_count(dv) * sizeof(T) + 16 : 0);
+  // two-pass costate sweep (WgCtx::sweep_costate_2pass), `chunks` of them: the end value of chunk 0 per instance, then one
+  // boundary record per instance for each of the chunks 1 .. chunks-2
+  static __host__ __device__ size_t scan2_count(int chunks) {
+    return size_t(IPW) * M::NX + size_t(chunks - 2) * IPW * SCAN_REC;
+  }
+  // scan_T: scalars of costate-sweep scratch behind the small arrays (scan_count(dv), scan2_count(chunks) or 0)
+  static __host__ __device__ size_t bytes(int dv, int kmax, int Lp, int Pp, int Hp, int plan = PLAN_FULL, size_t scan_T = 0) {
+    return count_T(dv, kmax, Lp, Pp, Hp, plan) * sizeof(T) + 4 * IPW * sizeof(int) + 16 + (scan_T ? scan_T * sizeof(T) + 16 : 0);
   }
   __device__ __forceinline__ WgLds(unsigned char* base, const WgParams<T>& P, int plan) {
     T* q = reinterpret_cast<T*>(base);
@@ -206,7 +213,10 @@ struct WgLds {
 };
 
 // Per-thread view of one workgroup's job.
-template <class M, class T, int IPW, int MAXM, bool LEAN = false, bool PAR = false>
+// PAR: form of the costate sweep — 0 serial (one lane per instance walks all stages), 1 chunk-parallel with per-stage
+// scratch in LDS (sweep_costate_par: full plans with short vectors), 2 chunk-parallel in two passes, boundary records only
+// (sweep_costate_2pass: every plan).
+template <class M, class T, int IPW, int MAXM, bool LEAN = false, int PAR = 0>
 struct WgCtx {
   using Lds = WgLds<M, T, IPW>;
   static constexpr int NSTG = Lds::NSTG;
@@ -822,10 +832,12 @@ struct WgCtx {
   __device__ __forceinline__ void sweep_costate(T dtau, const T* xT, T* out, bool only_active) {
     if constexpr (PAR_COSTATE) {
       sweep_costate_par<MODE>(dtau, xT, out, only_active);
+    } else if constexpr (PAR_2PASS) {
+      sweep_costate_2pass<MODE>(dtau, xT, out, only_active);
     } else {
       if (!(sweep_lane && (!only_active || S.flag[tid]))) return;
       T l[M::NX];
-      costate_run<MODE, false>(l, tid, P.dv - 1, P.dv, dtau, S.R + 2 * tid, out + tid * P.Lp,
+      costate_run<MODE, false, true>(l, tid, P.dv - 1, P.dv, dtau, S.R + 2 * tid, out + tid * P.Lp,
                                [&](T* l0) { costate_terminal(l0, xT, tid); });
     }
   }
@@ -847,7 +859,8 @@ struct WgCtx {
   //   After the `count` common stages, lanes with `more` set go on for `extra` (workgroup-uniform, 0..3) stages; the
   //   first two of those use operands the look-ahead has fetched anyway.  `init` fills l; it is called after the first
   //   operand requests have been issued so that its own LDS reads share their round trip.
-  template <int MODE, bool HOM, class Init>
+  //   WRITE = false: only the end value of l is wanted (first pass of sweep_costate_2pass): no output traffic at all.
+  template <int MODE, bool HOM, bool WRITE, class Init>
   __device__ __forceinline__ void costate_run(T* l, int i, int hi, int count, T dtau, const T* coef, T* orow, Init&& init,
                                               int extra = 0, bool more = false) {
     constexpr int NU = M::NU, NBW = M::NBW, NUL = M::NUL;
@@ -867,7 +880,7 @@ struct WgCtx {
         const Pair t = pp[(c / 2) * IPW];
         a.bw[c] = t.a, a.bw[c + 1] = t.b;
       }
-      if constexpr (!HOM) {
+      if constexpr (!HOM && WRITE) {
 #pragma unroll
         for (int j = 0; j < NUL; ++j) a.o[j] = po[j * OJ];
       }
@@ -875,8 +888,10 @@ struct WgCtx {
     auto stage = [&](const Ops& a, T* po) {
       T dF[NUL];
       M::template costate_step<HOM>(l, dF, a.bw, dtau);
+      if constexpr (WRITE) {
 #pragma unroll
-      for (int j = 0; j < NUL; ++j) po[j * OJ] = HOM ? dF[j] : a.o[j] + dF[j] * sc;
+        for (int j = 0; j < NUL; ++j) po[j * OJ] = HOM ? dF[j] : a.o[j] + dF[j] * sc;
+      }
     };
     // Three register sets, three stages per trip: the operands of stage t-2 are requested while stage t computes
     // (two LDS latencies of slack).  q/o sit on stage s-4 of the trip that starts with stage s: every access is
@@ -894,11 +909,11 @@ struct WgCtx {
 #endif
     auto fetch3 = [&](Ops& a, const T* pr3, const T* po3) {
       if (NLOAD) chk(pr3, 1), chk(pr3 + (NLOAD / 2 - 1) * 2 * IPW, 2);
-      if (!HOM) chk(po3, 3);
+      if (!HOM && WRITE) chk(po3, 3);
       fetch(a, pr3, po3);
     };
     auto stage3 = [&](const Ops& a, T* po3) {
-      chk(po3, 4);
+      if (WRITE) chk(po3, 4);
       stage(a, po3);
     };
     Ops A, B, C;
@@ -944,7 +959,9 @@ struct WgCtx {
   // PAR is a KERNEL TEMPLATE parameter, not a run-time switch: with both forms of the sweep in one kernel (or one body
   // with run-time chunk parameters) the register allocation of the Arnoldi loop tips over — two more spills inside the
   // loop, each reload behind an s_waitcnt vmcnt(0), cost 5 % of the tick (measured).
-  static constexpr bool PAR_COSTATE = PAR && M::COSTATE_HOM && !LEAN && IPW == 16 && M::NX * IPW <= 64 && M::NX % 2 == 0;
+  static constexpr bool PAR_OK = M::COSTATE_HOM && IPW == 16 && M::NX * IPW <= 64 && M::NX % 2 == 0;
+  static constexpr bool PAR_COSTATE = PAR == 1 && PAR_OK && !LEAN;
+  static constexpr bool PAR_2PASS = PAR == 2 && PAR_OK;
   template <int MODE>
   __device__ __forceinline__ void sweep_costate_par(T dtau, const T* xT, T* out, bool only_active) {
     constexpr int NX = M::NX, NU = M::NU, NUL = M::NUL;
@@ -966,7 +983,7 @@ struct WgCtx {
       if (item_on(i, only_active)) {
         T l[NX];
         const int hi = k == 0 ? dv - 1 : (4 - k) * n - 1;
-        costate_run<MODE, false>(l, i, hi, n, dtau, S.R + 2 * i, out + i * P.Lp,
+        costate_run<MODE, false, true>(l, i, hi, n, dtau, S.R + 2 * i, out + i * P.Lp,
                                  [&](T* l0) {
                                    costate_terminal(l0, xT, i);
                                    if (k != 0) {
@@ -985,7 +1002,7 @@ struct WgCtx {
       const int i = lane & (IPW - 1), c0 = lane / IPW, k = wave;
       if (item_on(i, only_active)) {
         T l[NX];
-        costate_run<MODE, true>(l, i, (4 - k) * n - 1, n, dtau, S.R + 2 * i, Hd + lane, [&](T* l0) {
+        costate_run<MODE, true, true>(l, i, (4 - k) * n - 1, n, dtau, S.R + 2 * i, Hd + lane, [&](T* l0) {
 #pragma unroll
           for (int c = 0; c < NX; ++c) l0[c] = c == c0 ? T(1) : T(0);
         });
@@ -1053,6 +1070,107 @@ struct WgCtx {
             *po = fma_t(acc, sc, *po);
           }
         }
+      }
+    }
+  }
+
+  // The chunk-parallel sweep WITHOUT per-stage scratch, for the plans whose LDS has no room for it (lean, long vectors):
+  // the horizon is cut into C = P.cs_chunks (3 or 4) chunks of n = dv/C stages (chunk 0, the LAST part of the horizon,
+  // takes the remainder) and walked twice —
+  //   pass 1 (no output traffic at all): wave 0, lane (k, i): chunk 0 from the terminal costate — its end value is the
+  //          start value of chunk 1 — and chunks 1 .. C-2 from l = 0 with the bias (particular end value p_k); waves 1..:
+  //          chunks 1 .. C-2 from the NX unit vectors without the bias (transfer matrix M_k).  The last chunk of the walk
+  //          (the first stages) needs neither: nobody continues from its end;
+  //   one barrier;
+  //   pass 2: wave 0, lane (k, i): l(start of chunk k) = p_(k-1) + M_(k-1) l(start of chunk k-1) (at most two small
+  //          products, redundantly per lane), then the chunk for real: o + sc*dF to `out` like the serial sweep.
+  // One wave walks 2n instead of dv stages, both times alone at the LDS pipe; the scratch is 4 + (C-2)*22 scalars per
+  // instance.  Same arithmetic per stage as the serial sweep; what differs is that l enters a chunk as p + M l_start
+  // instead of through the stages before it (rounding level, bounded against the oracle by the tests).
+  template <int MODE>
+  __device__ __forceinline__ void sweep_costate_2pass(T dtau, const T* xT, T* out, bool only_active) {
+    constexpr int NX = M::NX;
+    constexpr int REC = Lds::SCAN_REC;
+    static_assert(NX % 2 == 0, "boundary records are read in pairs");
+    const int C = P.cs_chunks, dv = P.dv, n = dv / C, n0 = dv - (C - 1) * n;  // chunk k >= 1: stages [(C-1-k)n, (C-k)n)
+    T* Vec0 = S.scan;              // [i][NX]
+    T* Rec = Vec0 + IPW * NX;      // [k-1][i][REC], k = 1 .. C-2
+    int tid_o = tid;               // (opaque: see sweep_costate_par)
+    asm volatile("" : "+v"(tid_o));
+    const int wave = tid_o >> 6, lane = tid_o & 63;
+    // ---- pass 1
+    if (wave == 0) {
+      const int i = lane & (IPW - 1), k = lane >> 4;
+      if (k < C - 1 && item_on(i, only_active)) {
+        T l[NX];
+        costate_run<MODE, false, false>(l, i, k == 0 ? dv - 1 : (C - k) * n - 1, n, dtau, S.R + 2 * i, out + i * P.Lp,
+                                        [&](T* l0) {
+                                          costate_terminal(l0, xT, i);
+                                          if (k != 0) {
+#pragma unroll
+                                            for (int c = 0; c < NX; ++c) l0[c] = T(0);
+                                          }
+                                        },
+                                        n0 - n, k == 0);
+        T* dst = k == 0 ? Vec0 + i * NX : Rec + ((k - 1) * IPW + i) * REC + NX * NX;
+#pragma unroll
+        for (int c = 0; c < NX; ++c) dst[c] = l[c];
+      }
+    } else {
+      const int q = tid_o - 64, g = q / HL, ql = q - g * HL, i = ql & (IPW - 1), c0 = ql / IPW;  // chunk g + 1, column c0
+      if (g < C - 2 && item_on(i, only_active)) {
+        T l[NX];
+        costate_run<MODE, true, false>(l, i, (C - 1 - g) * n - 1, n, dtau, S.R + 2 * i, out, [&](T* l0) {
+#pragma unroll
+          for (int c = 0; c < NX; ++c) l0[c] = c == c0 ? T(1) : T(0);
+        });
+#pragma unroll
+        for (int r = 0; r < NX; ++r) Rec[(g * IPW + i) * REC + r * NX + c0] = l[r];
+      }
+    }
+    CGM_STAMP(*this, 16);
+    lds_barrier();
+    CGM_STAMP(*this, 17);
+    // ---- pass 2
+    if (wave == 0) {
+      const int i = lane & (IPW - 1), k = lane >> 4;
+      if (k < C && item_on(i, only_active)) {
+        T l[NX];
+        costate_run<MODE, false, true>(l, i, k == 0 ? dv - 1 : (C - k) * n - 1, n, dtau, S.R + 2 * i, out + i * P.Lp,
+                                       [&](T* l0) {
+                                         if (k == 0) {
+                                           costate_terminal(l0, xT, i);
+                                         } else {
+                                           const Pair* v0 = reinterpret_cast<const Pair*>(Vec0 + i * NX);
+#pragma unroll
+                                           for (int c = 0; c < NX; c += 2) {
+                                             const Pair t = v0[c / 2];
+                                             l0[c] = t.a, l0[c + 1] = t.b;
+                                           }
+                                           for (int kk = 1; kk < k; ++kk) {  // l0 <- p_kk + M_kk l0
+                                             const Pair* rec = reinterpret_cast<const Pair*>(Rec + ((kk - 1) * IPW + i) * REC);
+                                             T m[NX * NX], nx[NX];
+#pragma unroll
+                                             for (int e = 0; e < NX * NX; e += 2) {
+                                               const Pair t = rec[e / 2];
+                                               m[e] = t.a, m[e + 1] = t.b;
+                                             }
+#pragma unroll
+                                             for (int c = 0; c < NX; c += 2) {
+                                               const Pair t = rec[(NX * NX + c) / 2];
+                                               nx[c] = t.a, nx[c + 1] = t.b;
+                                             }
+#pragma unroll
+                                             for (int rr = 0; rr < NX; ++rr) {
+#pragma unroll
+                                               for (int c = 0; c < NX; ++c) nx[rr] = fma_t(m[rr * NX + c], l0[c], nx[rr]);
+                                             }
+#pragma unroll
+                                             for (int c = 0; c < NX; ++c) l0[c] = nx[c];
+                                           }
+                                         }
+                                       },
+                                       n0 - n, k == 0);
       }
     }
   }
@@ -1575,7 +1693,7 @@ struct WgCtx {
 };
 
 // ---- the tick kernel: cgmres.hpp:78-110 for IPW instances ----------------------------------------
-template <class M, class T, int IPW, int MAXM, bool LEAN = false, bool PAR = false>
+template <class M, class T, int IPW, int MAXM, bool LEAN = false, int PAR = 0>
 __global__ __launch_bounds__(IPW * 16) __attribute__((amdgpu_waves_per_eu(LEAN ? 2 : 1, LEAN ? 2 : 1))) void tick_wg_kernel(
     WgParams<T> P) {
   extern __shared__ __align__(16) unsigned char smem[];

@@ -40,7 +40,7 @@ NAME = "pendulum" if MODEL == "pendulum32" else MODEL
 DT = "f32" if MODEL == "pendulum32" else "f64"
 x0, u0, p = scenarios.batch(NAME, B)
 c = cg.CgmresBatch(NAME, batch=B, dv=DV, k_max=KM, tol=0.0, dtype=DT)
-print("variant", c.variant, "B", B, "dv", DV, "kmax", KM, DT)
+print("variant", c.variant, c.variant_name, "B", B, "dv", DV, "kmax", KM, DT)
 x0, u0 = x0.astype(c.np_dtype), u0.astype(c.np_dtype)
 c.set_ptau_repeat(p); c.init_u0(u0); c.init_u0_newton(u0, x0, p, 10)
 xd = c.device_buffer(x0.shape).upload(x0); ud = c.device_buffer(u0.shape)
