@@ -37,7 +37,7 @@ else:
         for n in names:
             env = dict(os.environ)
             lib, _, sw = n.partition("@")  # name@serial: bench.py --flags 1 (CGMRES_HIP_FLAG_SERIAL_COSTATE)
-            extra = ["--flags", "1"] if sw == "serial" else []
+            extra = {"serial": ["--flags", "1"], "twopass": ["--flags", "8"], "": []}[sw]  # CGMRES_HIP_FLAG_*
             if lib != "base":
                 env["CGMRES_HIP_LIB"] = os.path.join(AB, lib, "lib.so")
             r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-ref-mode", "--steps", "150", "--warmup", "30"] + extra + os.environ.get("AB_BENCH_ARGS", "").split(),
