@@ -34,6 +34,9 @@ struct CtxWg final : cgmres_hip_ctx {
   size_t stage_n = 0, stage2_n = 0;
   T *x_dev = nullptr, *u_dev = nullptr;
   int fh_hbm_for_hooks = 0;
+  int* perm_dev = nullptr;   // placement of the next fused launch (bin_by_count_kernel)
+  bool binning = false;      // closed loop: bin the instances by their last Arnoldi count before every launch
+  bool have_counts = false;  // n_ax holds the counts of a finished tick
 
   int par_costate = 0;  // 0 serial, 1 chunk-parallel with LDS scratch, 2 two-pass (WgCtx::PAR)
   const char* variant_name() const override {
@@ -191,8 +194,13 @@ struct CtxWg final : cgmres_hip_ctx {
         (rc = dalloc(&P.pT, lean ? size_t((cfg.batch + ipw - 1) / ipw) * (cfg.dv + 1) * (np ? np : 1) * ipw : 1)) ||
         (rc = dalloc(&P.park, (maxm > 10 || lean) ? size_t((cfg.batch + ipw - 1) / ipw) * ipw * P.Lv : 1)) ||
         (rc = dalloc(&P.n_ax, B)) || (rc = dalloc(&P.reason, B)) || (rc = dalloc(&x_dev, B * nx)) ||
-        (rc = dalloc(&u_dev, B * nu)))
+        (rc = dalloc(&u_dev, B * nu)) || (rc = dalloc(&perm_dev, B)))
       return rc;
+    // Binning pays only when the batch needs more workgroups than the GPU holds at once (then the device works through
+    // a queue of workgroups and the sum of their times counts); with every workgroup resident the launch lasts as long
+    // as its slowest workgroup wherever the instances sit.  Early exits need tol > 0.
+    binning = cfg.tol > 0 && !(cfg.flags & CGMRES_HIP_FLAG_NO_BINNING) &&
+              (cfg.batch + ipw - 1) / ipw > cus * (lean ? 2 : 1);
     HIP_TRY(hipStreamSynchronize(stream));
     return 0;
   }
@@ -299,7 +307,14 @@ struct CtxWg final : cgmres_hip_ctx {
     for (int i = 0; i < n_ticks && !rc; i += CGM_FUSE_MAX) {
       const int n = n_ticks - i < CGM_FUSE_MAX ? n_ticks - i : CGM_FUSE_MAX;
       P.ptau_seq = seq ? seq + size_t(i) * per_tick : nullptr;  // the kernel reloads ptau at the top of every tick
+      if (binning && have_counts) {
+        bin_by_count_kernel<0><<<1, 1024, 0, stream>>>(perm_dev, P.n_ax, cfg.batch, cfg.k_max);
+        HIP_TRY(hipGetLastError());
+        P.perm = perm_dev;
+      }
       rc = launch_ticks(static_cast<T*>(u), static_cast<const T*>(x), static_cast<T*>(x), n);
+      P.perm = nullptr;
+      have_counts = true;
     }
     P.ptau_seq = nullptr;
     if (!rc && seq && n_ticks > 0) {  // the handle keeps the last tick's ptau, as set_ptau would (cgmres.hpp:36-39)

@@ -72,6 +72,11 @@ struct WgParams {
   T* pT;                               // lean plan: [workgroups][(dv+1)*NP][IPW] parameter horizon, transposed
   T* park;                             // [workgroups*IPW][Lv]: the solution vector during the Arnoldi loop (MAXM > 10 only)
   int *n_ax, *reason;
+  // Placement: slot q = workgroup*IPW + row of the launch holds instance perm[q] (null = identity).  Instances never
+  // exchange data, so any placement gives the same bits per instance; the closed loop of an oversubscribed batch bins
+  // instances by the Arnoldi count of their last tick so that the rows of a workgroup leave the loop together
+  // (gmres.hpp:93-95 makes the count data-dependent; util_kernels.hip.h: bin_by_count_kernel).
+  const int* perm;
   const T* x_in;  // [B][NX]
   T* u_out;       // [B][NU]
   T* x_next;      // [B][NX] or null
@@ -150,6 +155,7 @@ struct WgLds {
   T *U, *Fh, *W, *R, *p, *H, *rho, *g, *xs, *xh, *xT, *u0;  // xT: terminal states of the state sweeps in flight
   T* scan;  // scratch of the chunk-parallel costate sweep (WgCtx::sweep_costate_par), full plans only
   int *flag, *reason, *nax, *ksolve;
+  int* binst;  // global instance of every row of this workgroup (WgParams::perm applied)
   static __host__ __device__ size_t tab_count(int dv) { return size_t(dv + TAB_PAD) * NSTG * IPW; }
   static __host__ __device__ size_t count_T(int dv, int kmax, int Lp, int Pp, int Hp, int plan = PLAN_FULL) {
     const int k1 = kmax + 1;
@@ -173,7 +179,7 @@ struct WgLds {
   }
   // scan_T: scalars of costate-sweep scratch behind the small arrays (scan_count(dv), scan2_count(chunks) or 0)
   static __host__ __device__ size_t bytes(int dv, int kmax, int Lp, int Pp, int Hp, int plan = PLAN_FULL, size_t scan_T = 0) {
-    return count_T(dv, kmax, Lp, Pp, Hp, plan) * sizeof(T) + 4 * IPW * sizeof(int) + 16 + (scan_T ? scan_T * sizeof(T) + 16 : 0);
+    return count_T(dv, kmax, Lp, Pp, Hp, plan) * sizeof(T) + 5 * IPW * sizeof(int) + 16 + (scan_T ? scan_T * sizeof(T) + 16 : 0);
   }
   __device__ __forceinline__ WgLds(unsigned char* base, const WgParams<T>& P, int plan) {
     T* q = reinterpret_cast<T*>(base);
@@ -204,10 +210,10 @@ struct WgLds {
       u0 = q;
     }
     int* z = reinterpret_cast<int*>(q);
-    flag = z, reason = z + IPW, nax = z + 2 * IPW, ksolve = z + 3 * IPW;
+    flag = z, reason = z + IPW, nax = z + 2 * IPW, ksolve = z + 3 * IPW, binst = z + 4 * IPW;
     // 16-byte aligned (records are read in pairs) — as an OFFSET from the base: a pointer-integer-pointer round trip
     // loses the LDS address space and every access through `scan` becomes a flat load behind s_waitcnt vmcnt(0)
-    const unsigned scan_off = unsigned(reinterpret_cast<unsigned char*>(z + 4 * IPW) - base);
+    const unsigned scan_off = unsigned(reinterpret_cast<unsigned char*>(z + 5 * IPW) - base);
     scan = reinterpret_cast<T*>(base + ((scan_off + 15u) & ~15u));
   }
 };
@@ -234,16 +240,18 @@ struct WgCtx {
   bool sweep_lane;      // this thread runs the serial sweeps (for instance `tid`)
   T dtau_h, dtau_0;     // horizon steps of the current tick: F(., t+h) and F(., t)
   int bi;               // global instance of the sweep lane
+  int rot_level = 0, rot_hold = 0;  // quad sweep: form of the trig update the sweeps of this wave currently take (sweep_state)
   typename M::template MathFor<LEAN> mc;  // per-thread math context (pinned sin/cos constants); A/B: keeping it live for the whole
                         // kernel is 13 us/tick FASTER than re-creating it inside every sweep
   __device__ __forceinline__ WgCtx(const WgParams<T>& P_, unsigned char* smem)
       : P(P_), S(smem, P_, LEAN ? PLAN_LEAN : (MAXM > 10 && P_.fh_hbm ? PLAN_FH_HBM : PLAN_FULL)), tid(threadIdx.x),
         inst(threadIdx.x >> 4), r(threadIdx.x & 15) {
     pTw = LEAN ? P.pT + size_t(blockIdx.x) * (P.dv + 1) * (M::NP > 0 ? M::NP : 1) * IPW : nullptr;
-    b = blockIdx.x * IPW + inst;
-    valid = b < P.B;
-    bi = blockIdx.x * IPW + tid;
-    sweep_lane = tid < IPW && bi < P.B;
+    const int q = blockIdx.x * IPW + inst, qs = blockIdx.x * IPW + tid;  // slots of this row / of the sweep lane
+    valid = q < P.B;
+    sweep_lane = tid < IPW && qs < P.B;
+    b = (valid && P.perm) ? P.perm[q] : q;
+    bi = (sweep_lane && P.perm) ? P.perm[qs] : qs;
     dtau_h = P.dtau_h, dtau_0 = P.dtau_0;
     mc.init();
     CGM_STAMP(*this, -1);
@@ -405,6 +413,7 @@ struct WgCtx {
       S.reason[inst] = 0;
       S.nax[inst] = 0;
       S.ksolve[inst] = 0;
+      S.binst[inst] = b;
     }
   }
 
@@ -494,12 +503,19 @@ struct WgCtx {
       T ua = T(0);
       if (goq) ua = pu[0];
       // Stage modes: 0 = trig value rotated from the previous stage (PendulumDev::quad_stage_rot), 1 = fresh evaluation
-      // per stage (fast kernel), 2 = fresh evaluation with the library sin/cos.  A chunk starts in mode 0 from a fresh
-      // value and is redone in mode 1 when an angle increment left the rotation's range, in mode 2 when an argument left
-      // the fast kernel's range.
+      // per stage (fast kernel), 2 = fresh evaluation with the library sin/cos.  A chunk starts from a fresh value at the
+      // sweep's LEVEL (0: rotation, 1: fresh evaluations) and is redone one level up when an angle increment left the
+      // rotation's range, in mode 2 when an argument left the fast kernel's range.  The level is kept from sweep to
+      // sweep (rot_level: the perturbed sweeps of a tick and the ticks that follow see nearly the same increments —
+      // without that memory a batch in fast motion paid for a failed rotation pass in EVERY sweep: 176 instead of 145
+      // us/tick at tick 5500 of the seeded scenario, where the swing-up reaches 10 rad/s) and rotation is tried again
+      // every ROT_HOLD sweeps.  (A third form — rotation with one more Taylor term per polynomial, good to 0.145 rad per
+      // stage — was built and measured: its extra copy of the stage loop cost the slow regime 3.6 %; dropped.)
+      constexpr int ROT_HOLD = 64;
       T argp = T(0);
       int zmax = 0;
-      bool rot_ok = true;  // wave-uniform, per sweep: cleared by the first redo
+      int lvl = __builtin_amdgcn_readfirstlane(rot_level);  // wave-uniform (kept in a scalar register)
+      if (rot_hold == 0 && lvl > 0) lvl = 0, rot_hold = ROT_HOLD;
       auto run = [&](auto mode_tag, int n) {
         constexpr int MODE = decltype(mode_tag)::value;
         auto stage = [&](int o, T u0) {
@@ -541,47 +557,55 @@ struct WgCtx {
       };
       for (int s0 = 0; s0 < dv; s0 += CH) {
         const int n = dv - s0 < CH ? dv - s0 : CH;
-        if (goq) {
-          T xs[NX];
+        // (the level decisions are taken by ALL lanes of the wave, also those without an instance: the level stays
+        // wave-uniform and the stage loops never run under a divergent branch)
+        T xs[NX];
 #pragma unroll
-          for (int c = 0; c < NX; ++c) xs[c] = x[c];
-          auto rewind = [&]() {
+        for (int c = 0; c < NX; ++c) xs[c] = x[c];
+        auto rewind = [&]() {
 #pragma unroll
-            for (int c = 0; c < NX; ++c) x[c] = xs[c];
-            pa = tab + qi + s0 * STEP, pv = pa + Q.slot_v * IPW;
-            pu = U + s0 * NU;
-            ua = pu[0];
-          };
-          bool fresh = !rot_ok;  // wave-uniform: run this chunk with a fresh evaluation per stage
-          if (rot_ok) {
-            // the chunk starts from a fresh value (the sweep's first one comes from quad_begin)
-            if (s0 > 0) v = M::template quad_trig<false>(M::quad_arg(x, Q), Q, mc, &amax);
+          for (int c = 0; c < NX; ++c) x[c] = xs[c];
+          pa = tab + qi + s0 * STEP, pv = pa + Q.slot_v * IPW;
+          pu = U + s0 * NU;
+          if (goq) ua = pu[0];
+        };
+        bool stale_v = s0 > 0;  // the chunk starts from a fresh value (the sweep's first one comes from quad_begin)
+        bool done = false;
+        if (lvl == 0) {
+          if (goq) {
+            if (stale_v) v = M::template quad_trig<false>(M::quad_arg(x, Q), Q, mc, &amax);
             argp = M::quad_arg(x, Q);
             run(std::integral_constant<int, 0>{}, n);
-            if (__builtin_expect(__any(M::quad_rot_bad(zmax)), 0)) {  // an angle moved too far in one stage
-              fresh = true;
-              rot_ok = false;  // fast motion: the rest of this sweep evaluates afresh instead of paying for a rotation
-                               // pass AND its redo in every chunk
-            }
-            zmax = 0;
           }
-          if (__builtin_expect(fresh, 0)) {
-            rewind();  // (a no-op in effect when no rotation pass ran)
-            v = M::template quad_trig<false>(M::quad_arg(x, Q), Q, mc, &amax);
+          if (__builtin_expect(__any(goq && M::quad_rot_bad(zmax)), 0)) {  // an angle moved too far in one stage
+            lvl = 1, rot_hold = ROT_HOLD, stale_v = true;
+            rewind();
+          } else {
+            done = true;
+          }
+          zmax = 0;
+        }
+        if (__builtin_expect(!done, 0)) {
+          if (goq) {
+            if (stale_v) v = M::template quad_trig<false>(M::quad_arg(x, Q), Q, mc, &amax);
             run(std::integral_constant<int, 1>{}, n);
             if (n & 1) ua = pu[0];
           }
-          // an argument outside the fast range of the trig kernel: redo this chunk with the library sin/cos
-          if (__builtin_expect(__any(M::quad_arg_bad(amax)), 0)) {
-            rewind();
+        }
+        // an argument outside the fast range of the trig kernel: redo this chunk with the library sin/cos
+        if (__builtin_expect(__any(goq && M::quad_arg_bad(amax)), 0)) {
+          rewind();
+          if (goq) {
             v = M::template quad_trig<true>(M::quad_arg(x, Q), Q, mc, &amax);
             run(std::integral_constant<int, 2>{}, n);
             if (n & 1) ua = pu[0];
-            amax = T(0);
           }
+          amax = T(0);
         }
         if (PIPE) lds_barrier();
       }
+      rot_level = lvl;
+      if (rot_hold > 0) --rot_hold;
       if (goq && rho == M::QLANE_TRUE_X) {
 #pragma unroll
         for (int c = 0; c < NX; ++c) xT[c * IPW + qi] = x[c];
@@ -668,7 +692,7 @@ struct WgCtx {
       // explicitly global: left generic, hipcc merges this pointer with an LDS one and trips over the flat
       // aperture cast ("Illegal instruction detected ... $src_shared_base", ROCm 7.2)
       typedef const T __attribute__((address_space(1))) * GPtr;
-      const GPtr row = reinterpret_cast<GPtr>(reinterpret_cast<uintptr_t>(P.Fh)) + size_t(blockIdx.x * IPW + i) * P.Lg + s * M::NU;
+      const GPtr row = reinterpret_cast<GPtr>(reinterpret_cast<uintptr_t>(P.Fh)) + size_t(S.binst[i]) * P.Lg + s * M::NU;
 #pragma unroll
       for (int j = 0; j < M::NU; ++j) c.fh[j] = row[j];
     }

@@ -109,4 +109,36 @@ __global__ void probe_kernel(const double* x, const double* u, const double* p, 
   for (int j = 0; j < NU; ++j) out[3 * NX + j] = hu[j];
 }
 
+// Placement of an oversubscribed batch (WgParams::perm): instances grouped by the Arnoldi count of their last tick,
+// the long-running ones FIRST (the hardware hands workgroups out in index order, so the expensive ones start early and
+// the cheap ones fill the tail).  A counting sort of the B keys by one workgroup; the order inside a group is whatever
+// the atomics give — placement never changes an instance's bits.  key: n_ax[b] in 0..kmax (gmres.hpp:93-95).
+template <int UNUSED = 0>  // (a template: this header is included by several translation units)
+__global__ __launch_bounds__(1024) void bin_by_count_kernel(int* __restrict__ perm, const int* __restrict__ n_ax, int B, int kmax) {
+  __shared__ int cnt[66];
+  const int nb = kmax + 1 < 64 ? kmax + 1 : 64;
+  for (int q = threadIdx.x; q < 66; q += blockDim.x) cnt[q] = 0;
+  __syncthreads();
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    int k = n_ax[b];
+    k = k < 0 ? 0 : (k >= nb ? nb - 1 : k);
+    atomicAdd(&cnt[k], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {  // start offsets, largest count first
+    int off = 0;
+    for (int k = nb - 1; k >= 0; --k) {
+      const int c = cnt[k];
+      cnt[k] = off;
+      off += c;
+    }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    int k = n_ax[b];
+    k = k < 0 ? 0 : (k >= nb ? nb - 1 : k);
+    perm[atomicAdd(&cnt[k], 1)] = b;
+  }
+}
+
 }  // namespace cgm

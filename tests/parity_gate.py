@@ -79,6 +79,8 @@ class OracleSample:
         worst = 0.0
         self.flips = 0
         for j, i in enumerate(self.idx):
+            if not (np.all(np.isfinite(u[i])) and np.all(np.isfinite(x[i]))) and not np.all(np.isfinite(self.u[j])):
+                continue  # diverged on BOTH sides (the caller decides what a non-finite instance means)
             du = float(np.max(np.abs(np.asarray(u[i], dtype=np.float64) - self.u[j])))
             dx = float(np.max(np.abs(np.asarray(x[i], dtype=np.float64) - self.x[j])))
             worst = max(worst, du, dx)

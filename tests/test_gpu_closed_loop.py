@@ -233,3 +233,36 @@ def test_closed_loop_device_with_moving_reference(orc, model, variant, per_insta
         assert n_ax[i] == r.last_solve()[0]
         assert np.max(np.abs(u_next[i] - r.control(xi))) <= 1e-9, i
     sd.free(), xd.free(), ud.free(), c.close()
+
+
+def test_binned_placement_is_bit_identical(orc):
+    """Early-exit mode on a batch that needs more workgroups than the GPU holds at once: before every fused launch the
+    instances are re-placed by the Arnoldi count of their last tick (WgParams::perm, bin_by_count_kernel: an arbitrary
+    permutation inside a count group).  Instances never exchange data, so every instance must come out bit for bit as
+    in caller order (flags = FLAG_NO_BINNING) — 35 ticks = three re-placements and a partial tail."""
+    model, dv, km, B, n = 0, 50, 10, 8300, 35   # 519 sixteen-instance workgroups > 2 x 256 resident (lean plan)
+    x0, u0, p = orc.batch_scenario(model, B)
+    outs = []
+    for flags in (0, cg.FLAG_NO_BINNING):
+        c = cg.CgmresBatch(model, batch=B, dv=dv, k_max=km, tol=1e-6, flags=flags)
+        assert c.variant == 3
+        c.set_ptau_repeat(p)
+        c.init_u0(u0)
+        c.init_u0_newton(u0, x0, p, 10)
+        xd = c.device_buffer((B, 4)).upload(x0)
+        ud = c.device_buffer((B, 3))
+        c.closed_loop_device(xd, ud, n)
+        c.synchronize()
+        outs.append((xd.download(), ud.download(), c.get_state(), c.get_status()))
+        xd.free(), ud.free(), c.close()
+    a, b = outs
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(a[2][1], b[2][1]) and np.array_equal(a[2][2], b[2][2])
+    assert np.array_equal(a[3][0], b[3][0]) and np.array_equal(a[3][1], b[3][1])
+    assert np.all(np.isfinite(a[1]))
+    # ... and a spread sample against the oracle's free-running loop
+    sample = sample_of(B, 10)
+    ol = OracleLoop(orc, model, dv, km, 1e-6, "f64", x0, u0, p, sample, {n})
+    for j, i in enumerate(sample):
+        assert np.max(np.abs(a[1][i] - ol.snap[n]["u"][j])) <= 1e-9 and np.max(np.abs(a[0][i] - ol.snap[n]["x"][j])) <= 1e-9
+        assert a[3][0][i] == ol.snap[n]["solve"][j][0]
