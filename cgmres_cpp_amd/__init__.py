@@ -26,7 +26,7 @@ TICKS_PER_LAUNCH = 10  # CGMRES_HIP_TICKS_PER_LAUNCH: closed_loop_device fuses t
 # every symbol include/cgmres_hip.h declares (tests/test_capi_symbols.py checks header == this == library)
 SYMBOLS = [
     "cgmres_hip_model_info", "cgmres_hip_default_config", "cgmres_hip_model_probe", "cgmres_hip_register_model",
-    "cgmres_hip_selftest_sincos",
+    "cgmres_hip_selftest_sincos", "cgmres_hip_register_operator", "cgmres_hip_operator_info", "cgmres_hip_gmres_user",
     "cgmres_hip_last_error",
     "cgmres_hip_device_count", "cgmres_hip_create", "cgmres_hip_destroy", "cgmres_hip_get_config", "cgmres_hip_variant_name",
     "cgmres_hip_set_ptau", "cgmres_hip_set_ptau_repeat", "cgmres_hip_init_u0", "cgmres_hip_init_u0_newton",
@@ -76,6 +76,9 @@ def load():
     lib.cgmres_hip_model_probe.argtypes = [i32, i32] + [C.POINTER(C.c_double)] * 5
     lib.cgmres_hip_selftest_sincos.argtypes = [i32, C.POINTER(C.c_double), i32, C.POINTER(C.c_double),
                                                C.POINTER(C.c_double)]
+    lib.cgmres_hip_register_operator.argtypes = [C.c_char_p, C.POINTER(i32)]
+    lib.cgmres_hip_operator_info.argtypes = [i32, C.POINTER(i32)]
+    lib.cgmres_hip_gmres_user.argtypes = [i32, i32, i32, i32, C.c_double, vp, vp, vp, vp, vp]
     lib.cgmres_hip_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
     lib.cgmres_hip_destroy.argtypes = [vp]
     lib.cgmres_hip_get_config.argtypes = [vp, C.POINTER(Config)]
@@ -149,6 +152,27 @@ def selftest_sincos(a, device=0):
     _check(load().cgmres_hip_selftest_sincos(device, a.ctypes.data_as(dp), a.size, s.ctypes.data_as(dp),
                                              c.ctypes.data_as(dp)))
     return s, c
+
+
+def gmres_user(op_id, x0, b, k_max, tol, params=None, device=0):
+    """Gmres::gmres(x, b) (reference include/gmres.hpp:28-112) with a registered device operator (plugin.register_operator)
+    for a batch of independent systems: x0, b [batch, len]; params [batch, n_params].  Returns (x, n_ax, reason)."""
+    d = (C.c_int32 * 2)()
+    _check(load().cgmres_hip_operator_info(op_id, d))
+    L, npar = d[0], d[1]
+    x = np.array(np.asarray(x0, dtype=np.float64).reshape(-1, L))
+    bb = np.ascontiguousarray(np.asarray(b, dtype=np.float64).reshape(-1, L))
+    B = len(x)
+    if len(bb) != B:
+        raise ValueError("x0 and b must have the same batch")
+    pp = None
+    if npar:
+        pp = np.ascontiguousarray(np.broadcast_to(np.asarray(params, dtype=np.float64).reshape(-1, npar), (B, npar)))
+    n_ax = np.empty(B, dtype=np.int32)
+    why = np.empty(B, dtype=np.int32)
+    _check(load().cgmres_hip_gmres_user(op_id, device, B, int(k_max), float(tol), pp.ctypes.data if npar else None,
+                                        x.ctypes.data, bb.ctypes.data, n_ax.ctypes.data, why.ctypes.data))
+    return x, n_ax, why
 
 
 class DeviceBuffer:

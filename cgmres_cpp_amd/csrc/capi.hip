@@ -44,6 +44,23 @@ const Plugin* find_plugin(int id) {
   return n >= 0 && n < int(plugins().size()) ? &plugins()[n] : nullptr;
 }
 
+// Device operators registered at run time (cgmres_hip_register_operator): ids 0, 1, ...
+struct OpPlugin {
+  void* dl;
+  std::string path;
+  int32_t len, n_params;
+  int (*solve)(int32_t, int32_t, int32_t, double, const double*, double*, const double*, int32_t*, int32_t*);
+  const char* (*last_error)(void);
+};
+std::deque<OpPlugin>& op_plugins() {
+  static std::deque<OpPlugin> v;
+  return v;
+}
+const OpPlugin* find_op(int id) {
+  std::lock_guard<std::mutex> g(plugins_mutex());
+  return id >= 0 && id < int(op_plugins().size()) ? &op_plugins()[id] : nullptr;
+}
+
 cgm::ModelInfo model_info(int id, bool* ok) {
   *ok = true;
   if (const Plugin* pl = find_plugin(id)) return pl->info;
@@ -234,6 +251,62 @@ int cgmres_hip_register_model(const char* plugin_path, int32_t* model_id) {
   plugins().push_back(pl);
   *model_id = CGMRES_HIP_MODEL_USER_BASE + int(plugins().size()) - 1;
   return 0;
+}
+
+int cgmres_hip_register_operator(const char* plugin_path, int32_t* op_id) {
+  if (!plugin_path || !op_id) return fail(CGMRES_HIP_EINVAL, "register_operator: null argument");
+  {
+    std::lock_guard<std::mutex> g(plugins_mutex());
+    for (size_t n = 0; n < op_plugins().size(); ++n)
+      if (op_plugins()[n].path == plugin_path) {
+        *op_id = int(n);
+        return 0;
+      }
+  }
+  void* dl = dlopen(plugin_path, RTLD_NOW | RTLD_LOCAL);
+  if (!dl) return fail(CGMRES_HIP_EINVAL, "register_operator: %s", dlerror());
+  auto abi = reinterpret_cast<int32_t (*)(void)>(dlsym(dl, "cgmres_hip_opplugin_abi"));
+  auto info = reinterpret_cast<void (*)(int32_t*)>(dlsym(dl, "cgmres_hip_opplugin_info"));
+  OpPlugin pl{};
+  pl.dl = dl, pl.path = plugin_path;
+  pl.solve = reinterpret_cast<decltype(pl.solve)>(dlsym(dl, "cgmres_hip_opplugin_solve"));
+  pl.last_error = reinterpret_cast<decltype(pl.last_error)>(dlsym(dl, "cgmres_hip_opplugin_last_error"));
+  if (!abi || !info || !pl.solve || !pl.last_error) {
+    dlclose(dl);
+    return fail(CGMRES_HIP_EINVAL, "register_operator: %s is not a cgmres_hip operator plugin", plugin_path);
+  }
+  if (abi() != CGMRES_HIP_ABI_VERSION) {
+    dlclose(dl);
+    return fail(CGMRES_HIP_EINVAL, "register_operator: plugin ABI %d, library has %d", abi(), CGMRES_HIP_ABI_VERSION);
+  }
+  int32_t dims[2];
+  info(dims);
+  pl.len = dims[0], pl.n_params = dims[1];
+  if (pl.len < 1 || pl.n_params < 0) {
+    dlclose(dl);
+    return fail(CGMRES_HIP_EINVAL, "register_operator: bad dimensions %d/%d", dims[0], dims[1]);
+  }
+  std::lock_guard<std::mutex> g(plugins_mutex());
+  op_plugins().push_back(pl);
+  *op_id = int(op_plugins().size()) - 1;
+  return 0;
+}
+
+int cgmres_hip_operator_info(int32_t op_id, int32_t dims[2]) {
+  const OpPlugin* pl = find_op(op_id);
+  if (!pl || !dims) return fail(CGMRES_HIP_EINVAL, "operator_info: unknown operator %d", op_id);
+  dims[0] = pl->len, dims[1] = pl->n_params;
+  return 0;
+}
+
+int cgmres_hip_gmres_user(int32_t op_id, int32_t device, int32_t batch, int32_t k_max, double tol, const double* params,
+                          double* x, const double* b, int32_t* n_ax, int32_t* reason) {
+  const OpPlugin* pl = find_op(op_id);
+  if (!pl) return fail(CGMRES_HIP_EINVAL, "gmres_user: unknown operator %d", op_id);
+  if (int rc = check_device(device)) return rc;
+  const int rc = pl->solve(device, batch, k_max, tol, params, x, b, n_ax, reason);
+  if (rc) cgm::g_err = pl->last_error();  // (the plugin has its own copy of the error string)
+  return rc;
 }
 
 int cgmres_hip_create(const cgmres_hip_config* cfg, cgmres_hip_handle* out) {

@@ -194,16 +194,18 @@ __device__ __forceinline__ int poison_nonfinite(T* x, int L, size_t ld) {
   return 4;
 }
 
-// Gmres::gmres — gmres.hpp:28-112, per lane, sequential reductions in index order.
+// Gmres::gmres — gmres.hpp:28-112, per lane, sequential reductions in index order, around ANY operator:
+// `ax(out, v)` is the reference's pure virtual Ax_func (gmres.hpp:26) — the controller's forward-difference product
+// (gmres_lane below) or a caller-supplied device functor (user_operator.hip.h).  Element-major vectors: element e of this
+// lane's instance at [e*ld]; Krylov arrays V[(kmax+1)*L], H[(kmax+1)^2] column-major ld kmax+1, rho[kmax+1], g[3*kmax].
 // Returns the exit reason; n_ax = Arnoldi mat-vecs executed inside the k loop.
-template <class M, class T>
-__device__ __forceinline__ int gmres_lane(const TickParams<T>& P, size_t ld, const LaneView<T>& A, T* x,
-                                          const T* b, int* n_ax_out) {
-  const int L = P.L, kmax = P.kmax, ldh = kmax + 1;
-  T* V = A.V;
+template <class T, class AxF>
+__device__ __forceinline__ int gmres_lane_core(int L, int kmax, T tol, size_t ld, T* V, T* Hm, T* rho, T* g, T* x,
+                                               const T* b, int* n_ax_out, AxF&& ax) {
+  const int ldh = kmax + 1;
   *n_ax_out = 0;
   // r0 = b - A x0, rho = ||r0||   gmres.hpp:33-37
-  ax_lane<M, T>(P, ld, A, V, x);
+  ax(V, x);
   T ss = 0;
   for (int e = 0; e < L; ++e) {
     const T r = b[size_t(e) * ld] - V[size_t(e) * ld];
@@ -211,9 +213,9 @@ __device__ __forceinline__ int gmres_lane(const TickParams<T>& P, size_t ld, con
     ss += r * r;
   }
   const T rho0 = sqrt_t<T>(ss);
-  A.rho[0] = rho0;
+  rho[0] = rho0;
   if (!finite_t(rho0)) return poison_nonfinite(x, L, ld);  // (no such test in the reference: NaNs propagate there)
-  if (rho0 < P.tol) return 2;  // gmres.hpp:39-41
+  if (rho0 < tol) return 2;  // gmres.hpp:39-41
   {
     const T inv = T(1.0) / rho0;  // gmres.hpp:44 via matrix.hpp:122-128
     for (int e = 0; e < L; ++e) V[size_t(e) * ld] = V[size_t(e) * ld] * inv;
@@ -221,9 +223,9 @@ __device__ __forceinline__ int gmres_lane(const TickParams<T>& P, size_t ld, con
   int k, reason = 0;
   for (k = 0; k < kmax; ++k) {  // gmres.hpp:46
     T* w = V + size_t(L) * (k + 1) * ld;
-    ax_lane<M, T>(P, ld, A, w, V + size_t(L) * k * ld);  // :48
+    ax(w, V + size_t(L) * k * ld);  // :48
     *n_ax_out = k + 1;
-    T* Hk = A.H + size_t(ldh) * k * ld;
+    T* Hk = Hm + size_t(ldh) * k * ld;
     for (int i = 0; i <= k; ++i) {  // :52-58 modified Gram-Schmidt
       const T* vi = V + size_t(L) * i * ld;
       T hik = 0;
@@ -242,7 +244,7 @@ __device__ __forceinline__ int gmres_lane(const TickParams<T>& P, size_t ld, con
       for (int e = 0; e < L; ++e) w[size_t(e) * ld] = w[size_t(e) * ld] * inv;
     }
     for (int i = 0; i < k; ++i) {  // :71-77 stored reflectors
-      const T g0 = A.g[size_t(3 * i) * ld], g1 = A.g[size_t(3 * i + 1) * ld], g2 = A.g[size_t(3 * i + 2) * ld];
+      const T g0 = g[size_t(3 * i) * ld], g1 = g[size_t(3 * i + 1) * ld], g2 = g[size_t(3 * i + 2) * ld];
       const T a = Hk[size_t(i) * ld], c = Hk[size_t(i + 1) * ld];
       const T beta = (g0 * a + g1 * c) * g2;
       Hk[size_t(i) * ld] = a - beta * g0;
@@ -253,17 +255,17 @@ __device__ __forceinline__ int gmres_lane(const TickParams<T>& P, size_t ld, con
       const T sigma = -(a < T(0.0) ? T(-1.0) : T(1.0)) * sqrt_t<T>(a * a + c * c);
       const T g0 = a - sigma, g1 = c;
       const T g2 = T(2.0) / (g0 * g0 + g1 * g1);
-      A.g[size_t(3 * k) * ld] = g0;
-      A.g[size_t(3 * k + 1) * ld] = g1;
-      A.g[size_t(3 * k + 2) * ld] = g2;
+      g[size_t(3 * k) * ld] = g0;
+      g[size_t(3 * k + 1) * ld] = g1;
+      g[size_t(3 * k + 2) * ld] = g2;
       Hk[size_t(k) * ld] = sigma;
       Hk[size_t(k + 1) * ld] = T(0.0);
-      const T ek = A.rho[size_t(k) * ld];
+      const T ek = rho[size_t(k) * ld];
       const T beta = g0 * ek * g2;
-      A.rho[size_t(k) * ld] = ek - beta * g0;
+      rho[size_t(k) * ld] = ek - beta * g0;
       const T en = -beta * g1;
-      A.rho[size_t(k + 1) * ld] = en;
-      if (abs_t(en) < P.tol) {  // :93-95, k not incremented
+      rho[size_t(k + 1) * ld] = en;
+      if (abs_t(en) < tol) {  // :93-95, k not incremented
         reason = 1;
         break;
       }
@@ -271,17 +273,25 @@ __device__ __forceinline__ int gmres_lane(const TickParams<T>& P, size_t ld, con
   }
   // back substitution on the leading k x k block, gmres.hpp:100-107
   for (int i = k - 1; i >= 0; --i) {
-    T ei = A.rho[size_t(i) * ld];
-    for (int j = k - 1; j > i; --j) ei -= A.H[size_t(ldh * j + i) * ld] * A.rho[size_t(j) * ld];
-    A.rho[size_t(i) * ld] = ei / A.H[size_t(ldh * i + i) * ld];
+    T ei = rho[size_t(i) * ld];
+    for (int j = k - 1; j > i; --j) ei -= Hm[size_t(ldh * j + i) * ld] * rho[size_t(j) * ld];
+    rho[size_t(i) * ld] = ei / Hm[size_t(ldh * i + i) * ld];
   }
   // x += V[:,0:k] y, gmres.hpp:110-111 (accumulated j-ascending from 0 like matrix.hpp:82-91)
   for (int e = 0; e < L; ++e) {
     T acc = T(0.0);
-    for (int j = 0; j < k; ++j) acc += V[(size_t(L) * j + e) * ld] * A.rho[size_t(j) * ld];
+    for (int j = 0; j < k; ++j) acc += V[(size_t(L) * j + e) * ld] * rho[size_t(j) * ld];
     x[size_t(e) * ld] = x[size_t(e) * ld] + acc;
   }
   return reason;
+}
+
+// ... with the controller's forward-difference operator (cgmres.hpp:164-175)
+template <class M, class T>
+__device__ __forceinline__ int gmres_lane(const TickParams<T>& P, size_t ld, const LaneView<T>& A, T* x,
+                                          const T* b, int* n_ax_out) {
+  return gmres_lane_core<T>(P.L, P.kmax, P.tol, ld, A.V, A.H, A.rho, A.g, x, b, n_ax_out,
+                            [&](T* out, const T* v) { ax_lane<M, T>(P, ld, A, out, v); });
 }
 
 // ---- kernels ------------------------------------------------------------------------------------

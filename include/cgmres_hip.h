@@ -119,6 +119,19 @@ int cgmres_hip_model_probe(int32_t model_id, int32_t device, const double* x, co
  * (the affine costate split is generated from the user's own dHdx / dHdu, csrc/user_model.hip.h) and on the "lane"
  * mapping otherwise.  Registering the same path twice returns the same id.  This is what a `Cgmres<Model>` facade binds for a Model that is not in the registry. */
 int cgmres_hip_register_model(const char* plugin_path, int32_t* model_id);
+/* ---- stand-alone Gmres with a caller-supplied operator: class Gmres, reference include/gmres.hpp:8-129 ------------ */
+/* Registers a device OPERATOR: `plugin_path` is a shared object generated by cgmres_cpp_amd/plugin.py
+ * (build_operator) from a header with `struct Op { static constexpr int len, n_params; static void Ax(double* Ax,
+ * const double* x, const double* params); }` — the device build of a subclass's `Ax_func` (gmres.hpp:26).
+ * *op_id receives an id for cgmres_hip_gmres_user; the same path twice returns the same id. */
+int cgmres_hip_register_operator(const char* plugin_path, int32_t* op_id);
+/* dims[0] = len, dims[1] = n_params of a registered operator */
+int cgmres_hip_operator_info(int32_t op_id, int32_t dims[2]);
+/* Gmres::gmres(x, b) (gmres.hpp:28-112) for `batch` independent systems A(params_i) x_i = b_i, all with the same
+ * k_max and tol, on the GPU: x [batch][len] in/out (the warm start, :33), b [batch][len], params [batch][n_params]
+ * (NULL when n_params = 0); n_ax / reason [batch] as in cgmres_hip_get_status (NULL skips).  Host pointers; blocks. */
+int cgmres_hip_gmres_user(int32_t op_id, int32_t device, int32_t batch, int32_t k_max, double tol, const double* params,
+                          double* x, const double* b, int32_t* n_ax, int32_t* reason);
 /* Diagnostic: the device sin/cos the horizon sweeps use (fp64), evaluated at n host-supplied arguments. */
 int cgmres_hip_selftest_sincos(int32_t device, const double* a, int32_t n, double* s, double* c);
 const char* cgmres_hip_last_error(void);
