@@ -266,3 +266,39 @@ def test_binned_placement_is_bit_identical(orc):
     for j, i in enumerate(sample):
         assert np.max(np.abs(a[1][i] - ol.snap[n]["u"][j])) <= 1e-9 and np.max(np.abs(a[0][i] - ol.snap[n]["x"][j])) <= 1e-9
         assert a[3][0][i] == ol.snap[n]["solve"][j][0]
+
+
+def test_multiple_controller_at_baseline_size_vs_oracle(orc):
+    """BASELINE configs[3] as tools/bench_configs.py --config 4 runs it on one GPU: 4096 Model1 (MSD) + 4096 Model2
+    (pendulum) controllers, MultipleController picks the lean mapping by itself (512 workgroups for 256 CUs), the two
+    members' kernels are co-resident on the CUs (two workgroups of DIFFERENT kernels per CU).  25 ticks of the joint
+    device loop, a spread 24-instance sample of EACH member against the oracle's free-running loops
+    (multiple_controller/main.cpp:104-118)."""
+    from cgmres_cpp_amd.multi import MultipleController
+    n, dv, km, B = 25, 50, 10, 4096
+    mc = MultipleController([dict(model="msd", batch=B, dv=dv, k_max=km), dict(model="pendulum", batch=B, dv=dv, k_max=km)])
+    assert [m.variant for m in mc.members] == [3, 3]
+    xs, us, want = [], [], []
+    for m, model in zip(mc.members, (1, 0)):
+        x0, u0, p = orc.batch_scenario(model, B)
+        m.set_ptau_repeat(p)
+        m.init_u0(u0)
+        m.init_u0_newton(u0, x0, p, 10)
+        xs.append(m.device_buffer((B, m.dim_x)).upload(x0))
+        us.append(m.device_buffer((B, m.dim_u)))
+        sample = sample_of(B, 20)
+        want.append((sample, OracleLoop(orc, model, dv, km, 1e-6, "f64", x0, u0, p, sample, {n})))
+    mc.closed_loop_device(xs, us, n)
+    mc.synchronize()
+    for m, xd, ud, (sample, ol) in zip(mc.members, xs, us, want):
+        x, u = xd.download(), ud.download()
+        n_ax, reason = m.get_status()
+        assert np.all(np.isfinite(x)) and np.all(np.isfinite(u))
+        s = ol.snap[n]
+        assert len(sample) >= 24
+        for j, i in enumerate(sample):
+            assert np.max(np.abs(u[i] - s["u"][j])) <= 1e-9, (m.model, i)
+            assert np.max(np.abs(x[i] - s["x"][j])) <= 1e-9, (m.model, i)
+            assert n_ax[i] == s["solve"][j][0] and reason[i] == s["solve"][j][2]
+        xd.free(), ud.free()
+    mc.close()
