@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import isa_summary as isa  # noqa: E402
 
 SLOT_CYCLES = 4.4
-KERNEL = "_ZN3cgm14tick_wg_kernelINS_11PendulumDevIdEEdLi16ELi10ELb0ELb1EEEvNS_8WgParamsIT0_EE"  # (full plan, chunk-parallel costate)
+KERNEL = "_ZN3cgm14tick_wg_kernelINS_11PendulumDevIdEEdLi16ELi10ELb0ELi1EEEvNS_8WgParamsIT0_EE"  # (full plan, chunk-parallel costate)
 
 
 def stage_loops(asm):
