@@ -348,18 +348,19 @@ def main():
     n_check = args.check_sample if world == 1 else max(8, args.check_sample // world)
     inputs = shard_inputs(args.batch)
     m = measure(inputs, args.tol, args.steps, args.warmup, args.reps, n_check)
+    head = dict(resolved)  # (the mapping of the HEADLINE leg: the secondary legs below resolve their own)
     B = m["B"]
     value = args.batch * args.steps / m["wall"]
     ms_per_step = m["wall"] * 1e3 / args.steps
     # one launch of the wg mapping = TICKS_PER_LAUNCH consecutive ticks of the batch (the lane mapping: one tick)
-    tpl = cg.TICKS_PER_LAUNCH if resolved["variant"] in (2, 3) else 1  # (3 = wg-lean: same kernel, half the LDS)
+    tpl = cg.TICKS_PER_LAUNCH if head["variant"] in (2, 3) else 1  # (3 = wg-lean: same kernel, half the LDS)
     n_launches = -(-args.steps // tpl)
     launch_ms = m["kernel_ms"] / n_launches
     bytes_per_tick = float(sum(algorithmic_bytes(int(k)) for k in m["n_ax"])) if args.tol > 0 else \
         float(B * algorithmic_bytes(KMAX))
     bytes_per_launch = bytes_per_tick * args.steps / n_launches
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
-    traffic, traffic_src = committed_traffic(resolved["variant"], args.steps / n_launches, B) \
+    traffic, traffic_src = committed_traffic(head["variant"], args.steps / n_launches, B) \
         if args.tol == 0.0 else (None, None)
 
     def k_hist(n_ax):
@@ -397,7 +398,7 @@ def main():
         weak = {"scaling": "weak", "batch_per_gpu": mw["B"], "global_batch": args.batch * world,
                 "value": args.batch * world * args.steps / mw["wall"], "ms_per_step": mw["wall"] * 1e3 / args.steps}
 
-    kernel_name = "tick_lane_kernel" if resolved["variant"] == 1 else f"tick_wg_kernel [{resolved['variant_name']}]"
+    kernel_name = "tick_lane_kernel" if head["variant"] == 1 else f"tick_wg_kernel [{head['variant_name']}]"
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source_committed_profile": traffic_src,
                 "measured_GBps": (traffic / (launch_ms * 1e-3) / 1e9) if traffic else None,
@@ -421,8 +422,8 @@ def main():
         "config": {"workload": "arm_type_inverted_pendulum controllers, closed loop with on-device Euler plant",
                    "global_batch": args.batch, "batch_per_gpu": B, "N": DV, "kmax": KMAX, "tol": args.tol,
                    "mode": "fixed-k (tol=0, every instance runs k_max Arnoldi iterations)" if args.tol == 0
-                   else "reference early-exit", "variant": resolved["variant"],
-                   "variant_name": resolved["variant_name"],
+                   else "reference early-exit", "variant": head["variant"],
+                   "variant_name": head["variant_name"],
                    "parallelism": f"batch-shard x{world} (fixed global batch)" +
                                   ("" if args.backend == "nccl" else " [gloo rehearsal: ranks share GPUs]"),
                    "inputs": "splitmix64(12345) perturbed x0/targets, Newton-initialised U0 (SURVEY.md §8d)"},

@@ -104,7 +104,7 @@ def test_bench_gpus_2_from_a_plain_invocation_reaches_a_world_of_two():
 def test_bench_handles_every_wg_variant_in_its_bookkeeping():
     b = _bench()
     src = open(os.path.join(ROOT, "bench.py")).read()
-    assert 'resolved["variant"] in (2, 3)' in src          # wg-lean fuses 10 ticks per launch like wg
+    assert 'head["variant"] in (2, 3)' in src              # wg-lean fuses 10 ticks per launch like wg
     # committed PMC traffic is looked up per per-GPU batch and per LDS plan
     t, path = b.committed_traffic(2, 10, 4096)
     assert t and path.startswith("profiles/")
