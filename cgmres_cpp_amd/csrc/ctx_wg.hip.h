@@ -192,7 +192,7 @@ struct CtxWg final : cgmres_hip_ctx {
         (rc = dalloc(&P.ptau, B * size_t(np) * (cfg.dv + 1))) || (rc = dalloc(&P.kry, B * ks_all)) ||
         (rc = dalloc(&P.scr, size_t((cfg.batch + ipw - 1) / ipw) * 2 * (cfg.dv + WgLds<M, T, 16>::TAB_PAD) * WgLds<M, T, 16>::NSTG * ipw)) ||
         (rc = dalloc(&P.pT, lean ? size_t((cfg.batch + ipw - 1) / ipw) * (cfg.dv + 1) * (np ? np : 1) * ipw : 1)) ||
-        (rc = dalloc(&P.park, (maxm > 10 || lean) ? size_t((cfg.batch + ipw - 1) / ipw) * ipw * P.Lv : 1)) ||
+        (rc = dalloc(&P.park, size_t((cfg.batch + ipw - 1) / ipw) * ipw * P.Lv)) ||  // (every kernel family parks the solution vector now)
         (rc = dalloc(&P.n_ax, B)) || (rc = dalloc(&P.reason, B)) || (rc = dalloc(&x_dev, B * nx)) ||
         (rc = dalloc(&u_dev, B * nu)) || (rc = dalloc(&perm_dev, B)))
       return rc;

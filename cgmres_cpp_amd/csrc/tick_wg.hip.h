@@ -1438,6 +1438,16 @@ struct WgCtx {
   CGM_KCASE(f, 1) CGM_KCASE(f, 2) CGM_KCASE(f, 3) CGM_KCASE(f, 4) CGM_KCASE(f, 5) CGM_KCASE(f, 6) CGM_KCASE(f, 7) \
   CGM_KCASE(f, 8) CGM_KCASE(f, 9) CGM_KCASE(f, 10) CGM_KCASE(f, 11) CGM_KCASE(f, 12)
     constexpr int NBUF = MAXM <= 10 ? 3 : 2, KRING = 12;
+    // The first NKEEP basis vectors never leave the row lanes' registers (the compiler parks them in the AGPR file): v_0
+    // and v_1 are read again in every later iteration — 17 of the 55 Gram-Schmidt row reads of a k = 10 solve — and the
+    // Gram-Schmidt rounds are bounded by the CU's 64 B/clk vector-memory path, not by issue.  The ring then serves the
+    // rows from NKEEP on.  Pays for itself only where registers are left: the one-workgroup-per-CU kernels with short
+    // vectors, with the solution vector parked in HBM for the duration of the loop like the long-vector kernels do.
+#ifndef CGM_AB_NKEEP
+#define CGM_AB_NKEEP 2
+#endif
+    constexpr int NKEEP = (!LEAN && MAXM <= 10) ? CGM_AB_NKEEP : 0;
+    T vkeep[NKEEP > 0 ? NKEEP : 1][MAXM];
     // workgroup-uniform; longer bases use the plain streaming loop.  So does the lean plan: with 256 registers per wave the
     // twelve straight-line copies of the rounds push everything that lives across them (U, the sweep constants) into
     // scratch — in every block of the kernel, executed or not.
@@ -1447,7 +1457,7 @@ struct WgCtx {
     // push the Gram-Schmidt rounds into AGPR copies and scratch (profiles/r02_isa_summary.md).  Park it in HBM
     // (own row, same thread writes and reads it back: program order) and fetch it back behind the back substitution.
     T* const park_row = P.park + size_t(blockIdx.x * IPW + inst) * P.Lv;
-    constexpr bool PARK = MAXM > 10 || (LEAN && sizeof(T) == 8);  // (lean fp64: 256 registers per wave)
+    constexpr bool PARK = MAXM > 10 || (LEAN && sizeof(T) == 8) || NKEEP > 0;  // (lean fp64: 256 registers per wave)
     if constexpr (PARK) store_vec(park_row, xv);
     // r0 = b - A x0 ; rho = ||r0||      gmres.hpp:33-37
     {
@@ -1472,6 +1482,10 @@ struct WgCtx {
 #pragma unroll
         for (int m = 0; m < MAXM; ++m) vcur[m] = vcur[m] * inv;
         store_vec(vrow(0), vcur);
+        if constexpr (NKEEP > 0) {
+#pragma unroll
+          for (int m = 0; m < MAXM; ++m) vkeep[0][m] = vcur[m];
+        }
         publish_direction(vcur);
       }
       if (r == 0) S.flag[inst] = active ? 1 : 0;
@@ -1505,7 +1519,7 @@ struct WgCtx {
         if (preload && active) {
 #pragma unroll
           for (int i = 0; i < NBUF; ++i)
-            if (i < k) load_vec(vbuf[i], vrow(i));
+            if (i + NKEEP < k) load_vec(vbuf[i], vrow(i + NKEEP));
         }
       };
       if (tid >= 64) request_rows();
@@ -1540,8 +1554,14 @@ struct WgCtx {
             constexpr int K = decltype(kc)::value;
 #pragma unroll
             for (int i = 0; i < K; ++i) {
-              mgs_round(vbuf[i % NBUF], i);
-              if (i + NBUF < K) load_vec(vbuf[i % NBUF], vrow(i + NBUF));
+              if constexpr (NKEEP > 0) {
+                if (i < NKEEP) {
+                  mgs_round(vkeep[i < NKEEP ? i : 0], i);
+                  continue;
+                }
+              }
+              mgs_round(vbuf[(i - NKEEP) % NBUF], i);
+              if (i + NBUF < K) load_vec(vbuf[(i - NKEEP) % NBUF], vrow(i + NBUF));
             }
           };
           switch (k) {
@@ -1591,6 +1611,14 @@ struct WgCtx {
 #pragma unroll
           for (int m = 0; m < MAXM; ++m) vcur[m] = w[m] * inv;
           store_vec(vrow(k + 1), vcur);
+          if constexpr (NKEEP > 1) {
+#pragma unroll
+            for (int q = 1; q < NKEEP; ++q)
+              if (k + 1 == q) {
+#pragma unroll
+                for (int m = 0; m < MAXM; ++m) vkeep[q][m] = vcur[m];
+              }
+          }
           publish_direction(vcur);
           // Hessenberg column k: stored reflectors, new reflector, residual rotation (:71-90) — scalar work.
           // Every lane of the row computes it from the same LDS words (broadcast reads; a row never straddles
@@ -1622,7 +1650,7 @@ struct WgCtx {
     if (preload && valid && reason <= 1) {
 #pragma unroll
       for (int j = 0; j < NBUF; ++j)
-        if (j < ks) load_vec(vbx[j], vrow(j));
+        if (j + NKEEP < ks) load_vec(vbx[j], vrow(j + NKEEP));
     }
     if (valid && reason <= 1) {
       // back substitution (gmres.hpp:100-107), column-oriented over the lanes of the row: lane j owns e_j; step i
@@ -1665,9 +1693,16 @@ struct WgCtx {
 #pragma unroll
           for (int j = 0; j < K; ++j) {
             const T yj = rhoi[j];
+            if constexpr (NKEEP > 0) {
+              if (j < NKEEP) {
 #pragma unroll
-            for (int m = 0; m < MAXM; ++m) acc[m] += vbuf[j % NBUF][m] * yj;
-            if (j + NBUF < K) load_vec(vbuf[j % NBUF], vrow(j + NBUF));
+                for (int m = 0; m < MAXM; ++m) acc[m] += vkeep[j < NKEEP ? j : 0][m] * yj;
+                continue;
+              }
+            }
+#pragma unroll
+            for (int m = 0; m < MAXM; ++m) acc[m] += vbuf[(j - NKEEP) % NBUF][m] * yj;
+            if (j + NBUF < K) load_vec(vbuf[(j - NKEEP) % NBUF], vrow(j + NBUF));
           }
         };
         switch (ks) {
