@@ -332,8 +332,10 @@ struct PendulumDev {
     const T n0 = HOM ? fma_t(bw[0], l[3], l[0]) : (l[0] + bw[4]) + bw[0] * l[3];
     const T n1 = HOM ? fma_t(bw[1], l[3], l[1]) : (l[1] + bw[5]) + bw[1] * l[3];
     // (1 - dtau*As) and (1 - dtau*C22) are loop invariants of the sweep: 5 instructions for the two rows instead of 7
-    const T n2 = __builtin_fma(bw[2], l[3], __builtin_fma(dtau, l[0], (T(1.0) - dtau * As) * l[2]));
-    const T n3 = __builtin_fma(dtau, l[1], (T(1.0) - dtau * C22) * l[3]);
+    // (fma_t, not __builtin_fma: the latter is the DOUBLE builtin — in the fp32 kernels it cost 8 conversion / fp64
+    // instructions per stage of the costate loop, a quarter of it)
+    const T n2 = fma_t(bw[2], l[3], fma_t(dtau, l[0], (T(1.0) - dtau * As) * l[2]));
+    const T n3 = fma_t(dtau, l[1], (T(1.0) - dtau * C22) * l[3]);
     l[0] = n0, l[1] = n1, l[2] = n2, l[3] = n3;
   }
   // --- state sweep over a DPP quad -----------------------------------------------------------------
