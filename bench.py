@@ -251,8 +251,10 @@ def main():
         us, _, _, _ = orc.closed_loop(c, x0, ticks)
         return bool((~np.isfinite(us)).any() or np.nanmax(np.abs(us)) > 1e6)
 
-    def measure(inputs, tol, steps, warmup, reps, check, flags=None):
-        """Closed loop of this rank's shard: warm-up, then `reps` timed regions of exactly `steps` ticks."""
+    def measure(inputs, tol, steps, warmup, reps, check, flags=None, fatal=True):
+        """Closed loop of this rank's shard: warm-up, then `reps` timed regions of exactly `steps` ticks.
+        A failed parity gate ends the script (the headline: no number without parity) or, for a SECONDARY leg
+        (fatal=False), comes back as {"error": ...} so that the leg is reported as failed without a number."""
         x0_h, u0_h, p_h = inputs
         B = len(x0_h)
         ctrl = cg.CgmresBatch(MODEL, batch=B, dv=DV, k_max=KMAX, tol=tol, device=local, stream=stream,
@@ -333,6 +335,8 @@ def main():
         if err is not None or not finite:
             sys.stderr.write(f"[rank {rank}] PARITY FAILURE: {err or 'non-finite output'}\n")
         if bad.item():
+            if not fatal:
+                return {"error": err or ("non-finite output" if not finite else "parity failure on another rank")}
             if world > 1:
                 dist.destroy_process_group()
             sys.exit("parity check against the oracle failed: refusing to report a number")
@@ -369,6 +373,9 @@ def main():
     def early_exit_leg(m2, n_global, warm):
         """The reference's own mode (tol = 1e-6: the Arnoldi loop ends when |rho_e[k+1]| < tol, gmres.hpp:93-95), timed
         where the counts of the batch are SPREAD; bytes = sum of bytes(k_b) over the executed counts."""
+        if "error" in m2:
+            return {"tol": 1e-6, "warmup_ticks": warm, "global_batch": n_global, "value": None,
+                    "parity_failure": m2["error"], "note": "this leg failed its oracle gate: no number is reported for it"}
         by = float(sum(algorithmic_bytes(int(k)) for k in m2["n_ax"])) * world  # (this rank's shard x ranks)
         return {"tol": 1e-6, "warmup_ticks": warm, "global_batch": n_global, "variant_name": m2["variant_name"],
                 "value": n_global * args.steps / m2["wall"], "ms_per_step": m2["wall"] * 1e3 / args.steps,
@@ -376,12 +383,24 @@ def main():
                 "algorithmic_frac_of_peak": by / (m2["wall"] / args.steps) / 1e9 / HBM_PEAK_GBS / world,
                 "parity": m2["parity"]}
 
+    def soft(leg):
+        """A secondary leg must never cost the headline its line: anything it raises is reported inside the leg."""
+        try:
+            return leg()
+        except SystemExit:
+            raise
+        except Exception as e:  # noqa: BLE001 (reported, not swallowed)
+            if world > 1:
+                raise  # (ranks must stay in lock-step: a rank-local exception cannot be papered over)
+            return {"error": f"{type(e).__name__}: {e}"}
+
     ref_mode = binning = None
     if not args.no_ref_mode and args.tol == 0.0:
         reps2 = max(1, min(args.reps, 3))
-        ref_mode = early_exit_leg(measure(inputs, 1e-6, args.steps, args.ref_warmup, reps2, n_check), args.batch,
-                                  args.ref_warmup)
-        ref_mode["note"] = ("every workgroup is resident (one per CU): a launch lasts as long as its slowest workgroup, "
+        ref_mode = early_exit_leg(soft(lambda: measure(inputs, 1e-6, args.steps, args.ref_warmup, reps2, n_check,
+                                                       fatal=False)), args.batch, args.ref_warmup)
+        ref_mode.setdefault("note", "")
+        ref_mode["note"] += ("every workgroup is resident (one per CU): a launch lasts as long as its slowest workgroup, "
                             "so WHERE the instances sit cannot shorten it; placement by count is measured below on a "
                             "batch that needs several rounds of workgroups")
         if args.binning_batch and world == 1:
@@ -389,14 +408,18 @@ def main():
             legs = {}
             for name, fl in (("binned_by_last_count", args.flags & ~cg.FLAG_NO_BINNING),
                              ("caller_order", args.flags | cg.FLAG_NO_BINNING)):
-                legs[name] = early_exit_leg(measure(big, 1e-6, args.steps, args.ref_warmup, reps2, 8, fl),
-                                            args.binning_batch, args.ref_warmup)
-            binning = dict(legs, speedup=legs["binned_by_last_count"]["value"] / legs["caller_order"]["value"])
+                legs[name] = early_exit_leg(soft(lambda fl=fl: measure(big, 1e-6, args.steps, args.ref_warmup, reps2, 8, fl,
+                                                                       fatal=False)), args.binning_batch, args.ref_warmup)
+            both = legs["binned_by_last_count"]["value"] and legs["caller_order"]["value"]
+            binning = dict(legs, speedup=(legs["binned_by_last_count"]["value"] / legs["caller_order"]["value"]) if both else None)
     weak = None
     if world > 1 and not args.no_weak:
-        mw = measure(shard_inputs(args.batch * world), args.tol, args.steps, args.warmup, max(1, min(args.reps, 3)), 0)
-        weak = {"scaling": "weak", "batch_per_gpu": mw["B"], "global_batch": args.batch * world,
-                "value": args.batch * world * args.steps / mw["wall"], "ms_per_step": mw["wall"] * 1e3 / args.steps}
+        mw = measure(shard_inputs(args.batch * world), args.tol, args.steps, args.warmup, max(1, min(args.reps, 3)), 0,
+                     fatal=False)
+        weak = {"scaling": "weak", "global_batch": args.batch * world, "value": None, "parity_failure": mw["error"]} \
+            if "error" in mw else \
+            {"scaling": "weak", "batch_per_gpu": mw["B"], "global_batch": args.batch * world,
+             "value": args.batch * world * args.steps / mw["wall"], "ms_per_step": mw["wall"] * 1e3 / args.steps}
 
     kernel_name = "tick_lane_kernel" if head["variant"] == 1 else f"tick_wg_kernel [{head['variant_name']}]"
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
