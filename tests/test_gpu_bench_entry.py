@@ -30,3 +30,17 @@ def test_bench_gpus_2_self_launch_on_one_card():
     assert out["parity"]["instances_checked"] >= 8 and out["parity"]["continuation_1tick_max_err"] <= 1e-9
     assert out["weak_scaling"]["batch_per_gpu"] == 4096
     assert "cpu_baseline" not in out  # (rank 0 at N = 1 only)
+
+
+def test_bench_configs_gpus_2_self_launch_on_one_card():
+    """tools/bench_configs.py started like a single-GPU run with --gpus 2: same self-launch as bench.py; each member's
+    sub-batch is split over the ranks and every rank's members pass the oracle gate before the line is printed."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_configs.py"), "--gpus", "2", "--backend", "gloo",
+                        "--config", "4", "--steps", "20", "--warmup", "10", "--tols", "0", "--check-sample", "8"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["finite"]
+    assert lines[0]["members"] == ["msd B=4096 dv=50 k=10", "pendulum B=4096 dv=50 k=10"]
+    assert len(lines[0]["parity_rank0"]) == 2 and all(g["continuation_1tick_max_err"] <= 1e-9 for g in lines[0]["parity_rank0"])

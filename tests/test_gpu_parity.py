@@ -318,6 +318,29 @@ def test_chunk_parallel_costate_vs_serial_and_oracle(orc, model, dv, kmax, tol, 
     par.close(), ser.close()
 
 
+def test_eight_instances_per_workgroup_on_request(orc):
+    """flags = FLAG_IPW8: the 8-instance workgroups (otherwise taken only when 16 instances do not fit the LDS) on the
+    headline sizes, closed loop with early exits against the oracle."""
+    model, dv, km, B, n = 0, 50, 10, 100, 12
+    x0, u0, p = orc.batch_scenario(model, B)
+    c = cg.CgmresBatch(model, batch=B, dv=dv, k_max=km, tol=1e-6, variant=2, flags=cg.FLAG_IPW8)
+    assert c.variant_name == "wg"
+    c.set_ptau_repeat(p)
+    c.init_u0(u0)
+    c.init_u0_newton(u0, x0, p, 10)
+    refs = _oracle_batch(orc, model, dv, km, 1e-6, x0, u0, p)
+    x = x0.copy()
+    for tick in range(n):
+        u = c.control(x)
+        n_ax, reason = c.get_status()
+        for i, r in enumerate(refs):
+            ur = r.control(x[i])
+            assert np.max(np.abs(u[i] - ur)) <= U_TOL, (tick, i)
+            assert n_ax[i] == r.last_solve()[0] and reason[i] == r.last_solve()[2], (tick, i)
+            x[i] = x[i] + r.plant(x[i], ur) * r.dt
+    c.close()
+
+
 def test_chunk_parallel_costate_form_follows_the_lds_budget():
     """Which costate sweep a handle gets: the LDS-scratch form where its 23.5 KB fit (headline), the two-pass form with
     4 chunks where only boundary records fit (dim_u*dv = 159, k = 10; long vectors), with 3 chunks on the lean plan,
