@@ -1438,6 +1438,9 @@ struct WgCtx {
   CGM_KCASE(f, 1) CGM_KCASE(f, 2) CGM_KCASE(f, 3) CGM_KCASE(f, 4) CGM_KCASE(f, 5) CGM_KCASE(f, 6) CGM_KCASE(f, 7) \
   CGM_KCASE(f, 8) CGM_KCASE(f, 9) CGM_KCASE(f, 10) CGM_KCASE(f, 11) CGM_KCASE(f, 12)
     constexpr int NBUF = MAXM <= 10 ? 3 : 2, KRING = 12;
+    // row buffers of the streaming loops (lean kernels, k_max > KRING).  Three buffers were measured as well: the 256-register
+    // kernels then spill inside the Arnoldi loop (fp32 N = 100: 384 spilled VGPRs, cfg 5 526 -> 609 us/tick)
+    constexpr int SDEPTH = 2;
     // The first NKEEP basis vectors never leave the row lanes' registers (the compiler parks them in the AGPR file): v_0
     // and v_1 are read again in every later iteration — 17 of the 55 Gram-Schmidt row reads of a k = 10 solve — and the
     // Gram-Schmidt rounds are bounded by the CU's 64 B/clk vector-memory path, not by issue.  The ring then serves the
@@ -1574,18 +1577,31 @@ struct WgCtx {
           // The next row is requested UNCONDITIONALLY (the last trip re-reads its own row): a guard would be a branch
           // between a load and its use, and the compiler then waits with vmcnt(0) — i.e. also for the row it has just
           // requested, and nothing overlaps.
-          T vi[MAXM], vn[MAXM];
+          // SDEPTH row buffers with STATIC indices (no rotation by register moves: 20 v_mov per round, and a move would
+          // wait for the newest request): the main loop does SDEPTH rounds per trip and refills each buffer right after
+          // its round (row index clamped: the last trips re-read the last row), the remaining < SDEPTH rounds find
+          // their rows already requested.
+          T vq[SDEPTH][MAXM];
           const int kk = VK_IN_REGS ? k : k + 1;
-          if (kk > 0) load_vec(vi, vrow(0));
-          for (int i = 0; i < kk; ++i) {
-            load_vec(vn, vrow(i + 1 < kk ? i + 1 : i));
-            // (keeps the requests of the next row TOGETHER and ahead of the arithmetic on the current one: under register
-            // pressure the scheduler otherwise sinks every load next to its use — one exposed round trip per element)
-            __builtin_amdgcn_sched_barrier(0);
-            mgs_round(vi, i);
+          if (kk > 0) {
 #pragma unroll
-            for (int m = 0; m < MAXM; ++m) vi[m] = vn[m];
+            for (int d = 0; d < SDEPTH; ++d) load_vec(vq[d], vrow(d < kk ? d : kk - 1));
           }
+          int i = 0;
+          for (; i + SDEPTH <= kk; i += SDEPTH) {
+#pragma unroll
+            for (int d = 0; d < SDEPTH; ++d) {
+              // (keeps the requests TOGETHER and ahead of the arithmetic: under register pressure the scheduler otherwise
+              // sinks every load next to its use — one exposed round trip per element)
+              __builtin_amdgcn_sched_barrier(0);
+              mgs_round(vq[d], i + d);
+              const int nxt = i + d + SDEPTH;
+              load_vec(vq[d], vrow(nxt < kk ? nxt : kk - 1));
+            }
+          }
+#pragma unroll
+          for (int d = 0; d < SDEPTH - 1; ++d)
+            if (i + d < kk) mgs_round(vq[d], i + d);
         }
         if constexpr (VK_IN_REGS) mgs_round(vcur, k);
         T na = 0, nb = 0;
@@ -1710,18 +1726,30 @@ struct WgCtx {
           default: break;
         }
       } else {
-        // streaming form with the next row requested before the current one is used (two rows in flight)
-        T vj[MAXM], vn[MAXM];
-        if (ks > 0) load_vec(vj, vrow(0));
-        for (int j = 0; j < ks; ++j) {
-          load_vec(vn, vrow(j + 1 < ks ? j + 1 : j));  // unconditional: see the Gram-Schmidt loop
-          __builtin_amdgcn_sched_barrier(0);
+        // streaming form, SDEPTH rows in flight (see the Gram-Schmidt loop)
+        T vq[SDEPTH][MAXM];
+        if (ks > 0) {
+#pragma unroll
+          for (int d = 0; d < SDEPTH; ++d) load_vec(vq[d], vrow(d < ks ? d : ks - 1));
+        }
+        auto axpy = [&](const T* vj, int j) {
           const T yj = rhoi[j];
 #pragma unroll
           for (int m = 0; m < MAXM; ++m) acc[m] += vj[m] * yj;
+        };
+        int j = 0;
+        for (; j + SDEPTH <= ks; j += SDEPTH) {
 #pragma unroll
-          for (int m = 0; m < MAXM; ++m) vj[m] = vn[m];
+          for (int d = 0; d < SDEPTH; ++d) {
+            __builtin_amdgcn_sched_barrier(0);
+            axpy(vq[d], j + d);
+            const int nxt = j + d + SDEPTH;
+            load_vec(vq[d], vrow(nxt < ks ? nxt : ks - 1));
+          }
         }
+#pragma unroll
+        for (int d = 0; d < SDEPTH - 1; ++d)
+          if (j + d < ks) axpy(vq[d], j + d);
       }
 #pragma unroll
       for (int m = 0; m < MAXM; ++m) xv[m] = xv[m] + acc[m];
