@@ -67,7 +67,7 @@ struct CtxWg final : cgmres_hip_ctx {
   static constexpr bool kPar2 = M::COSTATE_HOM && M::NX * 16 <= 64 && M::NX % 2 == 0;
   template <int MAXM>
   static constexpr bool kParCostate = kPar2 && MAXM == 10;
-  static int pitch_H(int k_max) { return ((k_max * (k_max + 3)) / 2) | 1; }
+  static int pitch_H(int k_max) { return ((k_max * (k_max + 1)) / 2 + 2) | 1; }  // (+2: hess_column's look-ahead past the last column)
   // The costate sweep's look-ahead (WgCtx::costate_run) requests the coefficients of up to THREE stages below the first
   // stage of its range (the tail of the chunk-parallel form: `post` = 5) and the output words of those stages; the
   // values are never used, but the addresses must stay inside the workgroup's LDS allocation (an access outside it is

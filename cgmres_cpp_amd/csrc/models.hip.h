@@ -356,10 +356,10 @@ struct PendulumDev {
   // ONE 8-byte store carries four useful values: the d-lanes their sin d / cos d, the cos-x1 lane its value, and the
   // sin-x1 lane — whose own value no later phase reads — x1 instead (WgCtx::sweep_state: one select instead of a
   // second LDS store, which costs the issuing wave 14.6 cycles).  x0 and x2 (the same value in every lane) are
-  // written by all lanes, every other stage (see x02_step).  TAB_PAD: one spare stage behind the table (an earlier
-  // store scheme parked unused values there; the LDS carve-up behind the table was tuned with it in place).
+  // written by all lanes, every other stage (see x02_step).  (TAB_PAD: spare stages behind the table — none needed since
+  // every store lands in its own stage.)
   static constexpr bool HAS_QUAD_SWEEP = true;
-  static constexpr int NSLOT = 6, TRIG_SLOT0 = 3, TAB_PAD = 1;
+  static constexpr int NSLOT = 6, TRIG_SLOT0 = 3, TAB_PAD = 0;
   // x0 and x2 obey a recurrence of their own — x0' = x0 + dtau x2, x2' = x2 + dtau (-As x2 + Bs u0) (model.hpp:38,40) —
   // that needs no trig value.  In the pipelined sweeps the sweep wave therefore writes them to the stage table at every
   // OTHER stage only (an LDS store occupies the CU's LDS pipe for its 26 cycles whichever wave issues it), and the

@@ -153,6 +153,7 @@ struct WgLds {
   static constexpr int NSTG = M::NSLOT > M::NBW ? M::NSLOT : M::NBW;
   static constexpr int TAB_PAD = M::TAB_PAD;
   T *U, *Fh, *W, *R, *p, *H, *rho, *g, *xs, *xh, *xT, *u0;  // xT: terminal states of the state sweeps in flight
+  T* hsub;  // h(k+1,k) of the column in progress, per instance (the compact Hessenberg keeps rows 0..k of column k only)
   T* scan;  // scratch of the chunk-parallel costate sweep (WgCtx::sweep_costate_par), full plans only
   int *flag, *reason, *nax, *ksolve;
   int* binst;  // global instance of every row of this workgroup (WgParams::perm applied)
@@ -161,7 +162,7 @@ struct WgLds {
     const int k1 = kmax + 1;
     const int rows = plan == PLAN_FULL ? 3 : (plan == PLAN_FH_HBM ? 2 : 1);
     return size_t(rows) * IPW * Lp + tab_count(dv) + (plan == PLAN_LEAN ? 0 : size_t(IPW) * Pp) + size_t(IPW) * Hp +
-           size_t(IPW) * k1 + size_t(IPW) * 3 * kmax + size_t(plan == PLAN_LEAN ? 4 : 5) * M::NX * IPW +
+           size_t(IPW) * k1 + size_t(IPW) * 3 * kmax + size_t(IPW) + size_t(plan == PLAN_LEAN ? 4 : 5) * M::NX * IPW +
            (plan == PLAN_LEAN ? size_t(M::NU) * IPW : 0);
   }
   // chunk-parallel costate sweep (WgCtx::sweep_costate_par): dF of the homogeneous lanes for the 3*(dv/4) stages of
@@ -203,6 +204,7 @@ struct WgLds {
     H = q, q += IPW * P.Hp;
     rho = q, q += IPW * k1;
     g = q, q += IPW * 3 * P.kmax;
+    hsub = q, q += IPW;
     if (!lean) {
       xs = q, q += M::NX * IPW;
       xh = q, q += M::NX * IPW;
@@ -1389,14 +1391,15 @@ struct WgCtx {
   // Hessenberg column k of one instance: stored reflectors, new reflector, residual rotation (gmres.hpp:71-90) — scalar
   // work on the instance's small Krylov arrays in LDS.  hn = h(k+1,k).  Returns rho_e[k+1]; `writer` lanes store.
   __device__ __forceinline__ T hess_column(T* Hi, T* gi, T* rhoi, int k, T hn, bool writer) const {
-    T* Hk = Hi + ((k * (k + 3)) >> 1);
+    T* Hk = Hi + ((k * (k + 1)) >> 1);  // compact: column k = rows 0..k (h(k+1,k) arrives as `hn` and becomes 0)
     // The running entry stays in a register (a) and only ORIGINAL column entries / reflector words are read
     // from LDS, one step ahead: no store-to-load round trip through LDS between consecutive reflectors.
+    // (the look-ahead reads one or two words past the column: the next column / array, in bounds, never used)
     T a = Hk[0];
     T g0n = gi[0], g1n = gi[1], g2n = gi[2], cn = Hk[1];
     for (int i = 0; i < k; ++i) {
       const T g0 = g0n, g1 = g1n, g2 = g2n, c = cn;
-      g0n = gi[3 * i + 3], g1n = gi[3 * i + 4], g2n = gi[3 * i + 5], cn = Hk[i + 2];  // i+1 <= k: in range
+      g0n = gi[3 * i + 3], g1n = gi[3 * i + 4], g2n = gi[3 * i + 5], cn = Hk[i + 2];
       const T beta = (g0 * a + g1 * c) * g2;
       if (writer) Hk[i] = a - beta * g0;
       a = c - beta * g1;
@@ -1411,7 +1414,6 @@ struct WgCtx {
     if (writer) {
       gi[3 * k] = g0, gi[3 * k + 1] = g1, gi[3 * k + 2] = g2;
       Hk[k] = sigma;
-      Hk[k + 1] = T(0.0);
       rhoi[k] = ek - beta * g0;
       rhoi[k + 1] = en;
     }
@@ -1422,8 +1424,8 @@ struct WgCtx {
   // Out: xv updated.  All threads of the block must call this (it contains workgroup barriers).
   __device__ __forceinline__ void gmres(T* xv, const T* bb, const T* ax0) {
     const int kmax = P.kmax, k1 = kmax + 1;
-    T* Hi = S.H + inst * P.Hp;  // compact: column k has k+2 entries (rows 0..k+1) at offset k(k+3)/2
-    auto hoff = [](int k) { return (k * (k + 3)) >> 1; };
+    T* Hi = S.H + inst * P.Hp;  // compact: column k has k+1 entries (rows 0..k) at offset k(k+1)/2; h(k+1,k): S.hsub
+    auto hoff = [](int k) { return (k * (k + 1)) >> 1; };
     T* rhoi = S.rho + inst * k1;
     T* gi = S.g + inst * 3 * kmax;
     T vcur[MAXM], w[MAXM];
@@ -1530,7 +1532,7 @@ struct WgCtx {
         const int j = tid - 64;
         if (defer_hess && k > 0 && j >= 0 && j < IPW && S.reason[j] == 0 && S.nax[j] == k) {
           T* Hj = S.H + j * P.Hp;
-          hess_column(Hj, S.g + j * 3 * kmax, S.rho + j * k1, k - 1, Hj[hoff(k - 1) + k], true);
+          hess_column(Hj, S.g + j * 3 * kmax, S.rho + j * k1, k - 1, S.hsub[j], true);
         }
       };
       ax(true, request_rows, deferred_column);  // :48  W <- A v_k, in place
@@ -1613,7 +1615,7 @@ struct WgCtx {
         CGM_STAMP(*this, 7);
         const T hn = sqrt_t<T>(row16_sum(na + nb));  // :60
         if (r == 0) {
-          Hk[k + 1] = hn;
+          S.hsub[inst] = hn;
           S.nax[inst] = k + 1;
         }
         if (abs_t(hn) < T(DBL_EPSILON) || !finite_t(hn)) {  // :63-65 breakdown: x untouched; non-finite: x <- NaN below
@@ -1684,6 +1686,23 @@ struct WgCtx {
           e = r < i ? e - hji * yi : (r == i ? y : e);
         }
         if (r < ks) rhoi[r] = e;
+        if (r == 0) S.ksolve[inst] = ks;
+      } else if (kmax <= 31) {
+        // the same with TWO unknowns per lane (e_r and e_(r+16)): k_max = 20 of the long-horizon configuration — on lane 0
+        // alone the 200 dependent LDS steps of this solve were 2.7 % of that tick
+        T e0 = r < ks ? rhoi[r] : T(0), e1 = r + 16 < ks ? rhoi[r + 16] : T(0);
+        const int row_lane0 = (threadIdx.x & 63) & ~15;
+        for (int i = ks - 1; i >= 0; --i) {
+          // (rows beyond i + 1 read words of the following columns / arrays: in bounds, only used where the row is < i)
+          const T hii = Hi[hoff(i) + i], h0 = Hi[hoff(i) + r], h1 = Hi[hoff(i) + r + 16];
+          const bool hi_half = i >= 16;                           // (uniform) which of the lane's two unknowns e_i is
+          const T y = (hi_half ? e1 : e0) / hii;                  // meaningful in lane i & 15
+          const T yi = row_bcast(y, row_lane0 + (i & 15));
+          e0 = r < i ? e0 - h0 * yi : (r == i ? y : e0);
+          e1 = r + 16 < i ? e1 - h1 * yi : (r + 16 == i ? y : e1);
+        }
+        if (r < ks) rhoi[r] = e0;
+        if (r + 16 < ks) rhoi[r + 16] = e1;
         if (r == 0) S.ksolve[inst] = ks;
       } else if (r == 0) {
         for (int i = ks - 1; i >= 0; --i) {
@@ -1768,7 +1787,11 @@ struct WgCtx {
     const T* Hi = S.H + inst * P.Hp;  // compact columns -> the reference's (k_max+1) x (k_max+1) column-major array
     for (int q = r; q < k1 * k1; q += 16) {
       const int col = q / k1, row = q - col * k1;
-      dst[q] = (col < kmax && row <= col + 1) ? Hi[((col * (col + 3)) >> 1) + row] : T(0);
+      // rows 0..col from the compact columns; the subdiagonal entry is 0 once the column has been rotated (gmres.hpp:85) —
+      // a breakdown leaves at column nax-1 BEFORE its rotation (gmres.hpp:63-65): there it still holds h(k+1,k)
+      T v = (col < kmax && row <= col) ? Hi[((col * (col + 1)) >> 1) + row] : T(0);
+      if (row == col + 1 && col + 1 == S.nax[inst] && S.reason[inst] == 3) v = S.hsub[inst];
+      dst[q] = v;
     }
     for (int q = r; q < k1; q += 16) dst[k1 * k1 + q] = S.rho[inst * k1 + q];
     for (int q = r; q < 3 * kmax; q += 16) dst[k1 * k1 + k1 + q] = S.g[inst * 3 * kmax + q];

@@ -242,7 +242,7 @@ PAR_CASES = [
     (1, 50, 10, 1e-6, 35, "f64"),  # MSD at BASELINE size: L = 300 -> the long-vector kernels (MAXM = 20, fh_hbm plan)
     (0, 100, 20, 1e-6, 19, "f64"),  # pendulum N = 100: long vectors, four pipeline chunks in the state sweep
     (0, 100, 20, 1e-6, 33, "f32"),  # BASELINE configs[4] shape
-    (0, 53, 10, 0.0, 16, "f64"),   # dim_u*dv = 159, k = 10: no room for the LDS-scratch form -> two-pass by default
+    (0, 53, 12, 0.0, 16, "f64"),   # dim_u*dv = 159, k = 12: no room for the LDS-scratch form -> two-pass by default
 ]
 # how the parallel form is asked for -> (variant, flags, the name the handle must resolve to; None = whatever fits)
 PAR_FORMS = {
@@ -343,14 +343,14 @@ def test_eight_instances_per_workgroup_on_request(orc):
 
 def test_chunk_parallel_costate_form_follows_the_lds_budget():
     """Which costate sweep a handle gets: the LDS-scratch form where its 23.5 KB fit (headline), the two-pass form with
-    4 chunks where only boundary records fit (dim_u*dv = 159, k = 10; long vectors), with 3 chunks on the lean plan,
+    4 chunks where only boundary records fit (dim_u*dv = 159, k = 12; long vectors; the lean plans of the pendulum),
     the serial sweep on request or when not even those fit."""
     for kw, want in ((dict(model=0, dv=50, k_max=10, variant=2), "wg+parallel-costate"),
-                     (dict(model=0, dv=53, k_max=10, variant=2), "wg+two-pass-costate"),
+                     (dict(model=0, dv=53, k_max=12, variant=2), "wg+two-pass-costate"),
                      (dict(model=1, dv=50, k_max=10, variant=2), "wg+two-pass-costate"),
                      (dict(model=0, dv=50, k_max=10, variant=3), "wg-lean+two-pass-costate"),
                      (dict(model=0, dv=100, k_max=20, variant=3, dtype="f32"), "wg-lean+two-pass-costate"),
-                     (dict(model=1, dv=50, k_max=10, variant=3), "wg-lean"),   # 124 scalars of LDS left: records need 416
+                     (dict(model=1, dv=50, k_max=10, variant=3), "wg-lean"),   # 182 scalars of LDS left: the records of three chunks need 416
                      (dict(model=0, dv=50, k_max=10, variant=2, flags=cg.FLAG_SERIAL_COSTATE), "wg"),
                      (dict(model=0, dv=5, k_max=3, variant=3), "wg-lean")):
         c = cg.CgmresBatch(batch=16, tol=0.0, **kw)
