@@ -949,6 +949,7 @@ struct WgCtx {
     fetch3(A, q + 4 * STEP, o + 4 * opitch);  // stage hi
     fetch3(B, q + 3 * STEP, o + 3 * opitch);  // stage hi-1
     init(l);
+    if (!HOM && WRITE && PAR_COSTATE) CGM_STAMP(*this, 18);
     for (; rem >= 3; rem -= 3) {
       fetch3(C, q + 2 * STEP, o + 2 * opitch);
       stage3(A, o + 4 * opitch);
@@ -958,6 +959,7 @@ struct WgCtx {
       stage3(C, o + 2 * opitch);
       q -= 3 * STEP, o -= 3 * opitch;
     }
+    if (!HOM && WRITE && PAR_COSTATE) CGM_STAMP(*this, 19);
     // the last rem (0..2) common stages, then the extra ones of the lanes with `more`: A and B hold the next two
     const int post = rem + extra;  // <= 5
     if (post > 2) fetch3(C, q + 2 * STEP, o + 2 * opitch);
@@ -968,6 +970,7 @@ struct WgCtx {
     if (post >= 3 && more) stage3(C, o + 2 * opitch);
     if (post >= 4 && more) stage3(A, o + opitch);
     if (post >= 5 && more) stage3(B, o);
+    if (!HOM && WRITE && PAR_COSTATE) CGM_STAMP(*this, 20);
   }
 
   // The costate recurrence is AFFINE in l once the stage coefficients are stored (l' = M_s l + b_s, dF_s = B_s l), so
@@ -1292,6 +1295,7 @@ struct WgCtx {
       CGM_STAMP(*this, 4);
       sweep_coeffs<false, F_PLAIN>(dtau_h, S.R, S.W, false);  // in place: every entry of W is read (as u) before it is written
       __syncthreads();
+      CGM_STAMP(*this, 5);
       sweep_costate<F_PLAIN>(dtau_h, xT0, S.W, false);
       __syncthreads();
       {
@@ -1305,6 +1309,7 @@ struct WgCtx {
       __syncthreads();
       sweep_coeffs<false, F_RHS>(dtau_0, tab0, S.W, false);
       __syncthreads();
+      CGM_STAMP(*this, 5);
       sweep_costate<F_RHS>(dtau_0, xT1, S.W, false);
       __syncthreads();
       lds_to_reg(bb, S.W);
@@ -1334,6 +1339,7 @@ struct WgCtx {
       CGM_STAMP(*this, 4);
       sweep_coeffs<false, F_PLAIN>(dtau_h, S.R, S.Fh, false);  // (S.Fh is S.W itself when fh_hbm)
       __syncthreads();
+      CGM_STAMP(*this, 5);
       sweep_costate<F_PLAIN>(dtau_h, xT0, S.Fh, false);
       __syncthreads();
       if (fh_hbm()) {
@@ -1350,6 +1356,7 @@ struct WgCtx {
       if (WITH_AX0) {
         sweep_coeffs<true, F_AX>(dtau_h, tab1, S.W, false);
         __syncthreads();
+        CGM_STAMP(*this, 5);
         sweep_costate<F_AX>(dtau_h, xT2, S.W, false);
         __syncthreads();
         lds_to_reg(ax0, S.W);
@@ -1357,6 +1364,7 @@ struct WgCtx {
       }
       sweep_coeffs<false, F_RHS>(dtau_0, tab0, S.W, false);
       __syncthreads();
+      CGM_STAMP(*this, 5);
       sweep_costate<F_RHS>(dtau_0, xT1, S.W, false);
       __syncthreads();
       lds_to_reg(bb, S.W);
@@ -1443,6 +1451,16 @@ struct WgCtx {
     // row buffers of the streaming loops (lean kernels, k_max > KRING).  Three buffers were measured as well: the 256-register
     // kernels then spill inside the Arnoldi loop (fp32 N = 100: 384 spilled VGPRs, cfg 5 526 -> 609 us/tick)
     constexpr int SDEPTH = 2;
+    // The streaming loops end with a row request nobody consumes (their unconditional look-ahead).  In the kernels that
+    // ALSO carry the register ring (not lean: k_max picks the form at run time) the compiler must assume those registers
+    // are still being written wherever it reuses them on the ring path — it reuses them in the sweeps — and, the counter
+    // being in order, it put s_waitcnt vmcnt(0) at the start of wave 0's state sweep (draining the store of the new
+    // basis row) and at the start of its costate sweep (waiting for the ring rows requested just before, which are not
+    // needed until the Gram-Schmidt rounds).  Draining the look-ahead where the streaming loop ends keeps the ring path
+    // free of both: s_waitcnt vmcnt(0), other counters untouched.
+    auto drain_stream = [] {
+      if constexpr (!LEAN) __builtin_amdgcn_s_waitcnt(0x0F70);
+    };
     // The first NKEEP basis vectors never leave the row lanes' registers (the compiler parks them in the AGPR file): v_0
     // and v_1 are read again in every later iteration — 17 of the 55 Gram-Schmidt row reads of a k = 10 solve — and the
     // Gram-Schmidt rounds are bounded by the CU's 64 B/clk vector-memory path, not by issue.  The ring then serves the
@@ -1520,8 +1538,14 @@ struct WgCtx {
       // arrive while wave 0 sweeps); wave 0 — four waves' row requests take the CU's address unit ~800 cycles, which
       // would delay the sweep — does it after its state sweep, where it otherwise waits for the coefficient tail.
       T vbuf[NBUF][MAXM];
+      // (vmcnt(0) first: the two call sites below write the same registers, so without it the compiler must assume the
+      // other site's requests are still in flight — with an in-order counter and conditional requests that leaves it
+      // only s_waitcnt vmcnt(0) in front of EVERY row: each request waited for the previous row to arrive, on wave 0
+      // right after its state sweep.  What is really outstanding here is this thread's store of the newest basis row,
+      // at most.  Together with drain_stream: state phase -0.8 k cycles per sweep, headline 134.2 -> 133.1 us/tick.)
       auto request_rows = [&]() {
         if (preload && active) {
+          __builtin_amdgcn_s_waitcnt(0x0F70);
 #pragma unroll
           for (int i = 0; i < NBUF; ++i)
             if (i + NKEEP < k) load_vec(vbuf[i], vrow(i + NKEEP));
@@ -1604,6 +1628,7 @@ struct WgCtx {
 #pragma unroll
           for (int d = 0; d < SDEPTH - 1; ++d)
             if (i + d < kk) mgs_round(vq[d], i + d);
+          drain_stream();
         }
         if constexpr (VK_IN_REGS) mgs_round(vcur, k);
         T na = 0, nb = 0;
@@ -1769,6 +1794,7 @@ struct WgCtx {
 #pragma unroll
         for (int d = 0; d < SDEPTH - 1; ++d)
           if (j + d < ks) axpy(vq[d], j + d);
+        drain_stream();
       }
 #pragma unroll
       for (int m = 0; m < MAXM; ++m) xv[m] = xv[m] + acc[m];

@@ -33,11 +33,11 @@ if sys.argv[1] == "build":
 else:
     names = sys.argv[2:]
     res = {n: [] for n in names}
-    for rnd in range(3):
+    for rnd in range(int(os.environ.get("AB_ROUNDS", "3"))):
         for n in names:
             env = dict(os.environ)
             lib, _, sw = n.partition("@")  # name@serial: bench.py --flags 1 (CGMRES_HIP_FLAG_SERIAL_COSTATE)
-            extra = {"serial": ["--flags", "1"], "twopass": ["--flags", "8"], "": []}[sw]  # CGMRES_HIP_FLAG_*
+            extra = ["--flags", str(int(sw[2:], 0))] if sw.startswith("f=") else {"serial": ["--flags", "1"], "twopass": ["--flags", "8"], "": []}[sw]  # CGMRES_HIP_FLAG_*
             if lib != "base":
                 env["CGMRES_HIP_LIB"] = os.path.join(AB, lib, "lib.so")
             r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-ref-mode", "--steps", "150", "--warmup", "30"] + extra + os.environ.get("AB_BENCH_ARGS", "").split(),

@@ -52,7 +52,8 @@ N = 100
 c.closed_loop_device(xd, ud, N); c.synchronize()
 L.cgmres_hip_debug_stamps(out)
 names = {14: "loop top: before barrier_or", 15: "barrier_or (drains V row store)", 0: "prologue loads", 1: "preamble (2 sweeps)", 3: "ring preload issue", 4: "sweep phase 1 (state)",
-         5: "sweep phase 2 (coeffs)", 16: "costate A: four chunks side by side", 17: "costate: barrier",
+         5: "sweep phase 2 (coeffs)", 18: "costate A: prologue (terminal costate, first fetches)", 19: "costate A: stage loop", 20: "costate A: tail stages",
+         16: "costate A: four chunks side by side (record store when 18-20 are stamped)", 17: "costate: barrier",
          6: "sweep phase 3 (costate; B: boundaries + combine if chunk-parallel)", 7: "MGS rounds", 8: "norm+normalise+store",
          9: "Hessenberg scalar", 10: "loop exit barrier", 11: "back-subst", 12: "x update (V*y)", 13: "epilogue"}
 tot = out[29]; wall = out[28]
