@@ -112,6 +112,14 @@ def main():
                                "measured_cycles_per_stage": meas, "floor_over_measured": floor / meas,
                                "sweeps_per_tick_on_the_critical_path": visits, "share_of_tick": cyc / head["cycles_per_tick"],
                                "isa_loop": lp}
+        if name == "costate" and "costate A: stage loop" in ph:
+            # finer stamps (tools/phase_stamps.py ids 18-20): the stage loop alone — dv/4 common stages per sweep (3 per trip)
+            lc, lv = ph["costate A: stage loop"]
+            res["phases"][name]["stage_loop_alone"] = {
+                "stages": dv // 4, "measured_cycles_per_stage": lc / lv / (dv // 4), "floor_over_measured": floor / (lc / lv / (dv // 4)),
+                "note": "one stamp (~190 cycles) per sweep included; the rest of the phase is the prologue (flag, addresses, terminal "
+                        "costate, first fetches), the two tail stages of the direct chunk, the boundary-record store, the barrier and "
+                        "the combine phase B"}
         if name == "costate":
             res["phases"][name]["note"] = ("chunk-parallel sweep: wave 0 walks dv - 3*(dv/4) stages; the measured time also holds the "
                                            "barrier and the boundary/combine phase (~120 instructions per thread), which the per-stage floor does not count")
