@@ -242,6 +242,11 @@ struct WgCtx {
   bool sweep_lane;      // this thread runs the serial sweeps (for instance `tid`)
   T dtau_h, dtau_0;     // horizon steps of the current tick: F(., t+h) and F(., t)
   int bi;               // global instance of the sweep lane
+  // S.flag of the instances this thread works on in the sweeps of the current Arnoldi iteration — instance tid mod IPW
+  // (items of the coefficient and costate phases, the lane-per-instance state sweep) and instance (tid mod 64) / 4 (quad
+  // state sweep) — read once per iteration with the loop-top flag reads (gmres()) instead of one LDS round trip at the
+  // start of every phase; only meaningful where `only_active` is passed (the Arnoldi loop)
+  int act_i = 1, act_q = 1;
   int rot_level = 0, rot_hold = 0;  // quad sweep: form of the trig update the sweeps of this wave currently take (sweep_state)
   typename M::template MathFor<LEAN> mc;  // per-thread math context (pinned sin/cos constants); A/B: keeping it live for the whole
                         // kernel is 13 us/tick FASTER than re-creating it inside every sweep
@@ -263,32 +268,46 @@ struct WgCtx {
   // rows: HBM [B][Lg] -> LDS row / registers
   __device__ __forceinline__ void load_row_to_lds(T* lds, const T* g) const {
     if (!valid) return;
-#pragma unroll
-    for (int m = 0; m < MAXM; ++m) {
-      const int e = elem(m);
-      if (e < P.L) lds[inst * P.Lp + e] = g[size_t(b) * P.Lg + e];
-    }
+    const T* src = g + size_t(b) * P.Lg;
+    T* row = lds + inst * P.Lp;
+    each_elem([&](int m, auto full) {
+      if (decltype(full)::value || elem(m) < P.L) row[elem(m)] = src[elem(m)];
+    });
   }
   __device__ __forceinline__ void load_row_to_reg(T* reg, const T* g, size_t pitch) const {
+    const T* src = g + size_t(b) * pitch;
+    each_elem([&](int m, auto full) {
+      reg[m] = (valid && (decltype(full)::value || elem(m) < P.L)) ? src[elem(m)] : T(0);
+    });
+  }
+  // (Elements r + 16 m with m < L / 16 exist in every lane.  A per-lane guard on every element is an exec-mask sequence
+  // of ~8 instructions each — the masks live in spilled SGPRs — and lds_to_reg / publish_direction run in every Arnoldi
+  // iteration on every wave.  When all but the last two elements are full — L > 16 (MAXM - 2): what a kernel of this
+  // MAXM is normally chosen for — those are moved without a guard, in their own arm of a SCALAR branch (guards inside
+  // one loop, `m < L / 16 || e < L`, the compiler folds back into ten per-lane masks).)
+  static constexpr int MFAST = MAXM - 2;
+  __device__ __forceinline__ bool mostly_full() const { return (P.L >> 4) >= MFAST; }
+  template <class F>
+  __device__ __forceinline__ void each_elem(F&& f) const {  // f(m, full): full = element m exists in every lane
+    if (mostly_full()) {
 #pragma unroll
-    for (int m = 0; m < MAXM; ++m) {
-      const int e = elem(m);
-      reg[m] = (valid && e < P.L) ? g[size_t(b) * pitch + e] : T(0);
+      for (int m = 0; m < MFAST; ++m) f(m, std::true_type{});
+#pragma unroll
+      for (int m = MFAST; m < MAXM; ++m) f(m, std::false_type{});
+    } else {
+#pragma unroll
+      for (int m = 0; m < MAXM; ++m) f(m, std::false_type{});
     }
   }
   __device__ __forceinline__ void lds_to_reg(T* reg, const T* lds) const {
-#pragma unroll
-    for (int m = 0; m < MAXM; ++m) {
-      const int e = elem(m);
-      reg[m] = (e < P.L) ? lds[inst * P.Lp + e] : T(0);
-    }
+    const T* row = lds + inst * P.Lp;
+    each_elem([&](int m, auto full) { reg[m] = (decltype(full)::value || elem(m) < P.L) ? row[elem(m)] : T(0); });
   }
   __device__ __forceinline__ void reg_to_lds(T* lds, const T* reg) const {
-#pragma unroll
-    for (int m = 0; m < MAXM; ++m) {
-      const int e = elem(m);
-      if (e < P.L) lds[inst * P.Lp + e] = reg[m];
-    }
+    T* row = lds + inst * P.Lp;
+    each_elem([&](int m, auto full) {
+      if (decltype(full)::value || elem(m) < P.L) row[elem(m)] = reg[m];
+    });
   }
   // The direction d of a matrix-vector product is published to the sweeps as the perturbed control U + h*d
   // (cgmres.hpp:166-168 forms it in every stage); the sweep phases then read one array instead of two.
@@ -300,11 +319,10 @@ struct WgCtx {
 #pragma unroll
       for (int m = 0; m < MAXM; ++m) uu[m] = S.U[inst * P.Lp + elem(m)];
     }
-#pragma unroll
-    for (int m = 0; m < MAXM; ++m) {
-      const int e = elem(m);
-      if (e < P.L) S.W[inst * P.Lp + e] = reg[m] * P.h + uu[m];
-    }
+    T* row = S.W + inst * P.Lp;
+    each_elem([&](int m, auto full) {  // (see lds_to_reg)
+      if (decltype(full)::value || elem(m) < P.L) row[elem(m)] = reg[m] * P.h + uu[m];
+    });
   }
   // lean plan: the unperturbed sweeps read U through W as well
   __device__ __forceinline__ void publish_U() const {
@@ -325,11 +343,10 @@ struct WgCtx {
   }
   __device__ __forceinline__ void reg_to_row(T* g, size_t pitch, const T* reg) const {
     if (!valid) return;
-#pragma unroll
-    for (int m = 0; m < MAXM; ++m) {
-      const int e = elem(m);
-      if (e < P.L) g[size_t(b) * pitch + e] = reg[m];
-    }
+    T* dst = g + size_t(b) * pitch;
+    each_elem([&](int m, auto full) {
+      if (decltype(full)::value || elem(m) < P.L) dst[elem(m)] = reg[m];
+    });
   }
   __device__ __forceinline__ T* vrow(int j) const {  // Krylov vector j of this row's instance
     return P.V + (size_t(b) * (P.kmax + 1) + j) * P.Lv;
@@ -481,7 +498,7 @@ struct WgCtx {
       // entry — live across the whole tick they get spilled and every chunk of every sweep starts by waiting for
       // their scratch reloads (+5 k cycles per sweep); made opaque here they are ~12 selects per sweep call.
       if constexpr (LEAN) asm volatile("" : "+v"(rho));
-      const bool goq = lt < 4 * IPW && blockIdx.x * IPW + qi < P.B && (!only_active || S.flag[qi]);
+      const bool goq = lt < 4 * IPW && blockIdx.x * IPW + qi < P.B && (!only_active || act_q);
       typename M::QuadLane Q;
       Q.init(rho, mc);
       const T* __restrict__ U = (PERT || LEAN ? S.W : S.U) + qi * P.Lp;  // PERT: W holds U + h*direction (publish_direction)
@@ -614,7 +631,7 @@ struct WgCtx {
       }
     } else {
       const int i = lt;
-      const bool go = i < IPW && blockIdx.x * IPW + i < P.B && (!only_active || S.flag[i]);
+      const bool go = i < IPW && blockIdx.x * IPW + i < P.B && (!only_active || act_i);
       const T* __restrict__ U = (PERT || LEAN ? S.W : S.U) + i * P.Lp;  // (lean: W holds U for the unperturbed sweeps)
       T* __restrict__ R = tab + i;
       T xs[NX];
@@ -748,8 +765,9 @@ struct WgCtx {
     }
   }
   // all threads, items (s, i) with i fastest
+  // (i = tid mod IPW at every call site: the instance index of an item advances in steps that are multiples of IPW)
   __device__ __forceinline__ bool item_on(int i, bool only_active) const {
-    return blockIdx.x * IPW + i < P.B && (!only_active || S.flag[i]);
+    return blockIdx.x * IPW + i < P.B && (!only_active || act_i);
   }
   // items q0, q0 + stride, ... (COEFF_GROUP of them) of the range [0, n_items), stage offset s0: fetch, `between`, compute
   template <bool PERT, int MODE, class Between>
@@ -861,7 +879,7 @@ struct WgCtx {
     } else if constexpr (PAR_2PASS) {
       sweep_costate_2pass<MODE>(dtau, xT, out, only_active);
     } else {
-      if (!(sweep_lane && (!only_active || S.flag[tid]))) return;
+      if (!(sweep_lane && (!only_active || act_i))) return;
       T l[M::NX];
       costate_run<MODE, false, true>(l, tid, P.dv - 1, P.dv, dtau, S.R + 2 * tid, out + tid * P.Lp,
                                [&](T* l0) { costate_terminal(l0, xT, tid); });
@@ -1528,9 +1546,19 @@ struct WgCtx {
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
       {
+        // (16-byte reads, all requested before the first is used: left as IPW scalar reads the compiler issued them as
+        // eight ds_read2_b32 into ONE register pair, each behind s_waitcnt lgkmcnt(0) — eight LDS round trips in a row on
+        // every wave, at the top of every iteration.  The int arrays start on a 16-byte boundary: every array in front of
+        // them is a multiple of IPW scalars.)
+        static_assert(IPW % 4 == 0, "flags are read four at a time");
+        const int4* f4 = reinterpret_cast<const int4*>(__builtin_assume_aligned(S.flag, 16));
+        int4 fl[IPW / 4];
+#pragma unroll
+        for (int j = 0; j < IPW / 4; ++j) fl[j] = f4[j];
+        act_i = S.flag[tid & (IPW - 1)], act_q = S.flag[(tid & 63) >> 2];  // (IPW = 8: lanes 32.. read `reason` words, unused)
         int any = 0;
 #pragma unroll
-        for (int j = 0; j < IPW; ++j) any |= S.flag[j];
+        for (int j = 0; j < IPW / 4; ++j) any |= (fl[j].x | fl[j].y) | (fl[j].z | fl[j].w);
         if (!any) break;
       }
       CGM_STAMP(*this, 15);
