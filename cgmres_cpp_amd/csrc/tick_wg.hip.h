@@ -522,7 +522,7 @@ struct WgCtx {
       T ua = T(0);
       if (goq) ua = pu[0];
       // Stage modes: 0 = trig value rotated from the previous stage (PendulumDev::quad_stage_rot), 1 = fresh evaluation
-      // per stage (fast kernel), 2 = fresh evaluation with the library sin/cos.  A chunk starts from a fresh value at the
+      // per stage (fast kernel), 2 = fresh evaluation with the library sin/cos.  A chunk runs at the
       // sweep's LEVEL (0: rotation, 1: fresh evaluations) and is redone one level up when an angle increment left the
       // rotation's range, in mode 2 when an argument left the fast kernel's range.  The level is kept from sweep to
       // sweep (rot_level: the perturbed sweeps of a tick and the ticks that follow see nearly the same increments —
@@ -588,7 +588,11 @@ struct WgCtx {
           pu = U + s0 * NU;
           if (goq) ua = pu[0];
         };
-        bool stale_v = s0 > 0;  // the chunk starts from a fresh value (the sweep's first one comes from quad_begin)
+        // v (and with it the rotation) is carried from the previous chunk / quad_begin; only a redo starts from a fresh
+        // evaluation.  (Re-evaluating at every chunk start bounded the rotation's drift to one chunk — 26 stages at
+        // dv = 50 — at ~40 instructions per chunk; over the whole horizon the drift stays five orders below the parity
+        // bound, tests/test_gpu_parity.py.  126.8 -> 125.6 us/tick.)
+        bool stale_v = false;
         bool done = false;
         if (lvl == 0) {
           if (goq) {
