@@ -476,7 +476,13 @@ struct WgCtx {
   // Chunks of ~25 stages measured best (round 2, after the coefficient phase moved to stage pairs: 2 chunks at dv = 50 —
   // 1: -5 %, 3: -1.2 %, 4: -2.5 %, 5: -4 % — and 4 at dv = 100; round 1 had 4 at dv = 50): a barrier costs the sweep
   // wave ~300 cycles, and only the processing of the last chunk stays on the critical path.
+  // SPLIT_TAIL (full plans with the quad sweep, 16 instances): the LAST pipeline chunk is what the costate sweep waits
+  // for after the state sweep, so it is kept at SPLIT_N = 12 stages — 192 (stage, instance) items, ONE per lane of the
+  // three coefficient waves (coeffs_chunked) instead of a stage pair per lane — and the first chunk takes the rest
+  // (its coefficients are computed in the shadow of the sweep's last chunk either way).
+  static constexpr int SPLIT_N = 12;
   __device__ __forceinline__ int chunk_len() const {  // even: stages go in pairs
+    if (SPLIT_TAIL && P.dv <= 64 && P.dv >= 2 * SPLIT_N) return (P.dv - SPLIT_N + 1) & ~1;
     const int chunks = P.dv <= 64 ? 2 : 4;
     return 2 * ((P.dv + 2 * chunks - 1) / (2 * chunks));
   }
@@ -701,6 +707,7 @@ struct WgCtx {
   static constexpr bool HBM_OPERANDS = LEAN || MAXM > 10;  // kernels that carry the fh_hbm / lean code
   // the pipelined quad sweep stores x0 / x2 every other stage; the coefficient phase works on stage pairs
   static constexpr bool ALT_X02 = M::HAS_QUAD_SWEEP && IPW * 16 >= 128;
+  static constexpr bool SPLIT_TAIL = ALT_X02 && !HBM_OPERANDS && IPW == 16;
   static constexpr int COEFF_GROUP = sizeof(T) == 8 ? 2 : 3;
   struct CoeffPre {
     T p[M::NP > 0 ? M::NP : 1], fh[M::NU];
@@ -852,6 +859,24 @@ struct WgCtx {
           coeff_group<PERT, MODE>(q0, NL, n * IPW, s0, dtau, S.R, out, only_active, [] {});
       } else if constexpr (ALT_X02) {
         lds_barrier();
+        if (SPLIT_TAIL && n <= SPLIT_N) {
+          // One STAGE per lane: lanes 0-31 of a wave take the first stages of two pairs, lanes 32-63 their second stages
+          // (which re-derive x0 / x2 from the pair's first stage like the pair items do).  The coefficients of a stage
+          // overwrite its slots in place, and a second-stage lane reads two slots of the FIRST stage: both lanes sit in
+          // the same wave and every read below precedes every write in program order (straight-line code, no branch
+          // between the halves; a wave's LDS operations complete in order).
+          const int l = lt & 63, i = l & (IPW - 1), half = l >> 5;
+          const int ps = s0 + 2 * (2 * (lt >> 6) + ((l >> 4) & 1)), st = ps + half;
+          if (st < s0 + n && item_on(i, only_active)) {
+            T x02[2] = {S.R[(ps * NSTG + M::QSLOT_XA) * IPW + i], S.R[(ps * NSTG + M::QSLOT_XB) * IPW + i]};
+            const T u0 = (PERT || LEAN ? S.W : S.U)[i * P.Lp + ps * M::NU];
+            T x0n = x02[0], x2n = x02[1];
+            M::x02_step(x0n, x2n, u0, dtau);
+            if (half) x02[0] = x0n, x02[1] = x2n;
+            coeff_item<PERT, MODE>(st, i, dtau, S.R, out, nullptr, x02);
+          }
+          continue;
+        }
         for (int q = lt; q < ((n + 1) >> 1) * IPW; q += NL) {  // items = (stage pair, instance)
           const int i = q & (IPW - 1), s = s0 + 2 * (q / IPW);
           if (!item_on(i, only_active)) continue;
