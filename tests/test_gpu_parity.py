@@ -232,6 +232,9 @@ PAR_CASES = [
     (0, 50, 10, 1e-6, 40, "f64"),  # headline sizes: chunks of 12 stages, the direct chunk 14
     (0, 49, 10, 0.0, 33, "f64"),   # dv % 4 = 1
     (0, 47, 8, 1e-6, 17, "f64"),   # dv % 4 = 3
+    (0, 64, 8, 1e-6, 23, "f64"),   # pipeline chunks 52 + 12: the longest two-chunk horizon (one-stage-per-lane coefficient tail)
+    (0, 25, 6, 0.0, 21, "f64"),    # pipeline chunks 14 + 11: odd last chunk (its last pair has a first stage only)
+    (0, 24, 6, 1e-6, 19, "f64"),   # pipeline chunks 12 + 12: both take the one-stage-per-lane path
     (0, 16, 5, 1e-6, 20, "f64"),   # dv % 4 = 0, chunks of 4 stages
     (0, 7, 3, 1e-6, 18, "f64"),    # chunks of ONE stage (the look-ahead of the stage loop runs past them)
     (0, 4, 3, 0.0, 5, "f64"),      # the shortest horizon the LDS-scratch form takes (the two-pass form wants dv >= 6)
