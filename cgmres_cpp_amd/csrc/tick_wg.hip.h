@@ -708,6 +708,7 @@ struct WgCtx {
   // the pipelined quad sweep stores x0 / x2 every other stage; the coefficient phase works on stage pairs
   static constexpr bool ALT_X02 = M::HAS_QUAD_SWEEP && IPW * 16 >= 128;
   static constexpr bool SPLIT_TAIL = ALT_X02 && !HBM_OPERANDS && IPW == 16;
+  static_assert(!SPLIT_TAIL || IPW * 16 - 64 == 16 * 12, "SPLIT_N stages x 16 instances = the lanes of the three coefficient waves");
   static constexpr int COEFF_GROUP = sizeof(T) == 8 ? 2 : 3;
   struct CoeffPre {
     T p[M::NP > 0 ? M::NP : 1], fh[M::NU];
