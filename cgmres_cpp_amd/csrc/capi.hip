@@ -325,7 +325,7 @@ int cgmres_hip_create(const cgmres_hip_config* cfg, cgmres_hip_handle* out) {
   if (len >= 32768 || len * (cfg->k_max + 1) >= 65536)
     return fail(CGMRES_HIP_EINVAL, "dim_u*dv = %ld with k_max = %d exceeds the reference's 16-bit index range", len, cfg->k_max);
   if (!(cfg->h > 0) || !(cfg->dt > 0) || !(cfg->tol >= 0)) return fail(CGMRES_HIP_EINVAL, "h, dt must be > 0 and tol >= 0");
-  if (cfg->variant < 0 || cfg->variant > 3) return fail(CGMRES_HIP_EINVAL, "unknown variant %d", cfg->variant);
+  if (cfg->variant < 0 || cfg->variant > 4) return fail(CGMRES_HIP_EINVAL, "unknown variant %d", cfg->variant);
   if (cfg->flags & ~(CGMRES_HIP_FLAG_SERIAL_COSTATE | CGMRES_HIP_FLAG_IPW8 | CGMRES_HIP_FLAG_NO_BINNING | CGMRES_HIP_FLAG_TWO_PASS_COSTATE))
     return fail(CGMRES_HIP_EINVAL, "unknown flags 0x%x", cfg->flags);
   if (int rc = check_device(cfg->device)) return rc;

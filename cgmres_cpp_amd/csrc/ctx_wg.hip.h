@@ -4,6 +4,7 @@
 #include <vector>
 #include "ctx_common.hip.h"
 #include "tick_wg.hip.h"
+#include "tick_wave.hip.h"
 #include "util_kernels.hip.h"
 
 namespace cgm {
@@ -39,7 +40,18 @@ struct CtxWg final : cgmres_hip_ctx {
   bool have_counts = false;  // n_ax holds the counts of a finished tick
 
   int par_costate = 0;  // 0 serial, 1 chunk-parallel with LDS scratch, 2 two-pass (WgCtx::PAR)
+  // variant 4 ("wave", tick_wave.hip.h): one wavefront per controller; the tick kernel changes, the HBM state, the
+  // white-box hooks and everything else of this context stay those of the wg mapping
+  bool wave = false;
+  static constexpr int kWaveKmax = 10, kWaveWpb = 1;
+  size_t lds_bytes_tick() const { return wave ? WaveLds<M, T>::bytes(cfg.dv, cfg.k_max, kWaveWpb) : lds_bytes; }
+  static bool wave_supported(const cgmres_hip_config& c) {
+    if constexpr (WaveOps<M>::value && std::is_same<T, double>::value)
+      return c.dv >= 1 && c.dv <= 63 && c.k_max >= 1 && c.k_max <= kWaveKmax;
+    return false;
+  }
   const char* variant_name() const override {
+    if (wave) return "wave";
     static const char* const names[2][3] = {{"wg", "wg+parallel-costate", "wg+two-pass-costate"},
                                             {"wg-lean", "wg-lean", "wg-lean+two-pass-costate"}};
     return names[plan == PLAN_LEAN][par_costate];
@@ -147,9 +159,17 @@ struct CtxWg final : cgmres_hip_ctx {
     } else if (cfg.variant == 0 && lean_ok && (cfg.batch + 15) / 16 > cus) {
       lean = true;
     }
+    // the latency mapping: asked for, or (library's choice) when the batch leaves most of the GPU's SIMDs without a
+    // controller of their own on the wg mapping
+    if (cfg.variant == 4) {
+      if (!wave_supported(cfg)) return fail(CGMRES_HIP_EINVAL, "wave mapping: model / dtype / dv = %d / k_max = %d not supported", cfg.dv, cfg.k_max);
+      wave = true;
+    } else if (cfg.variant == 0 && wave_supported(cfg) && cfg.batch <= 4 * cus && !(cfg.flags & CGMRES_HIP_FLAG_NO_WAVE)) {
+      wave = true;
+    }
     if (lean) plan = PLAN_LEAN, fh_hbm = 0, lds_bytes = lean_bytes;
     else plan = fh_hbm ? PLAN_FH_HBM : PLAN_FULL;
-    cfg.variant = lean ? 3 : 2;
+    cfg.variant = wave ? 4 : (lean ? 3 : 2);
     const int fh_hbm_hook = lean ? [&] { int i, f = 0; size_t bb; supported(cfg, &i, &bb, &f); return f; }() : fh_hbm;
     const bool big = L > 160;
     // chunk-parallel costate sweep (WgCtx::sweep_costate_par): its own kernel instantiation on the full plan, taken when
@@ -173,8 +193,11 @@ struct CtxWg final : cgmres_hip_ctx {
     if (want == 16 && big) pick<16, 20>(lean, par);
     if (want == 8 && !big) pick<8, 10>(false, 0);
     if (want == 8 && big) pick<8, 20>(false, 0);
+    if constexpr (WaveOps<M>::value && std::is_same<T, double>::value) {
+      if (wave) k_tick = tick_wave_kernel<M, T, kWaveKmax, kWaveWpb>;
+    }
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                int(lds_bytes)));
+                                int(lds_bytes_tick())));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hook), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 int(lds_bytes_hook)));
     fh_hbm_for_hooks = fh_hbm_hook;
@@ -199,7 +222,7 @@ struct CtxWg final : cgmres_hip_ctx {
     // Binning pays only when the batch needs more workgroups than the GPU holds at once (then the device works through
     // a queue of workgroups and the sum of their times counts); with every workgroup resident the launch lasts as long
     // as its slowest workgroup wherever the instances sit.  Early exits need tol > 0.
-    binning = cfg.tol > 0 && !(cfg.flags & CGMRES_HIP_FLAG_NO_BINNING) &&
+    binning = !wave && cfg.tol > 0 && !(cfg.flags & CGMRES_HIP_FLAG_NO_BINNING) &&
               (cfg.batch + ipw - 1) / ipw > cus * (lean ? 2 : 1);
     HIP_TRY(hipStreamSynchronize(stream));
     return 0;
@@ -277,7 +300,10 @@ struct CtxWg final : cgmres_hip_ctx {
       t = t + P.dt;                          // cgmres.hpp:107
     }
     P.dtau_h = P.dtau_tab[0], P.dtau_0 = P.dtau_tab[1];
-    k_tick<<<grid(), block(), lds_bytes, stream>>>(P);
+    if (wave)
+      k_tick<<<dim3((cfg.batch + kWaveWpb - 1) / kWaveWpb), dim3(64 * kWaveWpb), lds_bytes_tick(), stream>>>(P);
+    else
+      k_tick<<<grid(), block(), lds_bytes, stream>>>(P);
     HIP_TRY(hipGetLastError());
     return 0;
   }

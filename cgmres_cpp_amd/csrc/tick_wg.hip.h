@@ -1446,7 +1446,7 @@ struct WgCtx {
 
   // Hessenberg column k of one instance: stored reflectors, new reflector, residual rotation (gmres.hpp:71-90) — scalar
   // work on the instance's small Krylov arrays in LDS.  hn = h(k+1,k).  Returns rho_e[k+1]; `writer` lanes store.
-  __device__ __forceinline__ T hess_column(T* Hi, T* gi, T* rhoi, int k, T hn, bool writer) const {
+  static __device__ __forceinline__ T hess_column(T* Hi, T* gi, T* rhoi, int k, T hn, bool writer) {
     T* Hk = Hi + ((k * (k + 1)) >> 1);  // compact: column k = rows 0..k (h(k+1,k) arrives as `hn` and becomes 0)
     // The running entry stays in a register (a) and only ORIGINAL column entries / reflector words are read
     // from LDS, one step ahead: no store-to-load round trip through LDS between consecutive reflectors.

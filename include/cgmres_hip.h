@@ -70,7 +70,8 @@ enum {
   CGMRES_HIP_FLAG_SERIAL_COSTATE = 1, /* wg mapping: keep the one-lane-per-instance costate sweep (no chunk-parallel scan) */
   CGMRES_HIP_FLAG_IPW8 = 2,           /* wg mapping: 8 instead of 16 instances per workgroup where that fits */
   CGMRES_HIP_FLAG_NO_BINNING = 4,     /* closed loop: keep instances in caller order inside the workgroups (no k-binning) */
-  CGMRES_HIP_FLAG_TWO_PASS_COSTATE = 8 /* wg mapping: the two-pass chunk-parallel costate sweep also where the LDS-scratch form fits */
+  CGMRES_HIP_FLAG_TWO_PASS_COSTATE = 8, /* wg mapping: the two-pass chunk-parallel costate sweep also where the LDS-scratch form fits */
+  CGMRES_HIP_FLAG_NO_WAVE = 16         /* library's choice of mapping: never the wave mapping (small batches stay on wg) */
 };
 
 /* cgmres_hip_closed_loop_device advances up to this many consecutive ticks per kernel launch (the controller
@@ -88,8 +89,9 @@ typedef struct cgmres_hip_config {
   int32_t k_max;       /* Model::k_max GMRES iterations */
   int32_t device;      /* HIP device ordinal */
   int32_t variant;     /* kernel mapping: 0 = library's choice, 1 = "lane", 2 = "wg" (one workgroup per CU: everything
-                          of 16 instances in LDS), 3 = "wg-lean" (half the LDS, two workgroups per CU);
-                          get_config returns the resolved value */
+                          of 16 instances in LDS), 3 = "wg-lean" (half the LDS, two workgroups per CU),
+                          4 = "wave" (one wavefront per controller, horizon recurrences as wave scans: the latency
+                          mapping for batches smaller than the GPU); get_config returns the resolved value */
   int32_t flags;       /* CGMRES_HIP_FLAG_* (0 = library defaults) */
   int32_t reserved;    /* 0 */
   double tol;          /* Model::tol */
@@ -142,7 +144,7 @@ int cgmres_hip_device_count(void);
 int cgmres_hip_create(const cgmres_hip_config* cfg, cgmres_hip_handle* out);
 int cgmres_hip_destroy(cgmres_hip_handle h);
 int cgmres_hip_get_config(cgmres_hip_handle h, cgmres_hip_config* cfg);
-/* Name of the mapping / kernel family the handle resolved to: "lane", "wg", "wg-lean", "wg+parallel-costate", "wg+two-pass-costate", "wg-lean+two-pass-costate" (static
+/* Name of the mapping / kernel family the handle resolved to: "lane", "wave", "wg", "wg-lean", "wg+parallel-costate", "wg+two-pass-costate", "wg-lean+two-pass-costate" (static
  * string; NULL on an invalid handle).  No counterpart in the reference: for logs and for tests that must know which
  * instantiation they exercised. */
 const char* cgmres_hip_variant_name(cgmres_hip_handle h);
