@@ -326,8 +326,10 @@ int cgmres_hip_create(const cgmres_hip_config* cfg, cgmres_hip_handle* out) {
     return fail(CGMRES_HIP_EINVAL, "dim_u*dv = %ld with k_max = %d exceeds the reference's 16-bit index range", len, cfg->k_max);
   if (!(cfg->h > 0) || !(cfg->dt > 0) || !(cfg->tol >= 0)) return fail(CGMRES_HIP_EINVAL, "h, dt must be > 0 and tol >= 0");
   if (cfg->variant < 0 || cfg->variant > 4) return fail(CGMRES_HIP_EINVAL, "unknown variant %d", cfg->variant);
-  if (cfg->flags & ~(CGMRES_HIP_FLAG_SERIAL_COSTATE | CGMRES_HIP_FLAG_IPW8 | CGMRES_HIP_FLAG_NO_BINNING | CGMRES_HIP_FLAG_TWO_PASS_COSTATE))
+  if (cfg->flags & ~(CGMRES_HIP_FLAG_SERIAL_COSTATE | CGMRES_HIP_FLAG_IPW8 | CGMRES_HIP_FLAG_NO_BINNING | CGMRES_HIP_FLAG_TWO_PASS_COSTATE |
+                     CGMRES_HIP_FLAG_NO_WAVE | CGMRES_HIP_FLAG_WAVE_FRESH_TRIG | CGMRES_HIP_FLAG_WAVE_SERIAL_SWEEPS))
     return fail(CGMRES_HIP_EINVAL, "unknown flags 0x%x", cfg->flags);
+  if (cfg->reserved != 0) return fail(CGMRES_HIP_EINVAL, "cgmres_hip_config.reserved must be 0 (got %d)", cfg->reserved);
   if (int rc = check_device(cfg->device)) return rc;
   int resolved = 0;
   cgmres_hip_ctx* c = make_ctx(*cfg, &resolved);
@@ -371,12 +373,16 @@ int cgmres_hip_init_u0_newton(cgmres_hip_handle h, void* u0, const void* x0, con
   NEED(h);
   return h->init_u0_newton(u0, x0, p0, n_loop);
 }
+// The reference's DEBUG_MODE builds exit(-1) when an output argument aliases an input (cgmres.hpp:119-124,
+// matrix.hpp:76-81); at the ABI the same calls are refused.
 int cgmres_hip_control(cgmres_hip_handle h, void* u, const void* x) {
   NEED(h);
+  if (u && u == x) return fail(CGMRES_HIP_EINVAL, "control: u and x are the same buffer (cgmres.hpp DEBUG_MODE alias guard)");
   return h->control_host(u, x);
 }
 int cgmres_hip_control_device(cgmres_hip_handle h, void* u, const void* x) {
   NEED(h);
+  if (u && u == x) return fail(CGMRES_HIP_EINVAL, "control_device: u and x are the same buffer (cgmres.hpp DEBUG_MODE alias guard)");
   return h->control_device(u, x, nullptr);
 }
 int cgmres_hip_closed_loop_device(cgmres_hip_handle h, void* x, void* u, int32_t n_ticks) {
@@ -421,6 +427,7 @@ int cgmres_hip_get_krylov(cgmres_hip_handle h, void* V, void* H, void* rho, void
 int cgmres_hip_F_func(cgmres_hip_handle h, void* ret, const void* U, const void* x, double t) {
   NEED(h);
   if (!ret || !U || !x) return fail(CGMRES_HIP_EINVAL, "F_func: null pointer");
+  if (ret == U || ret == x) return fail(CGMRES_HIP_EINVAL, "F_func: ret aliases an input (cgmres.hpp:119-124)");
   return h->hook_F(ret, U, x, t);
 }
 int cgmres_hip_prepare(cgmres_hip_handle h, void* b, const void* x) {
@@ -431,11 +438,13 @@ int cgmres_hip_prepare(cgmres_hip_handle h, void* b, const void* x) {
 int cgmres_hip_Ax_func(cgmres_hip_handle h, void* out, const void* v) {
   NEED(h);
   if (!out || !v) return fail(CGMRES_HIP_EINVAL, "Ax_func: null pointer");
+  if (out == v) return fail(CGMRES_HIP_EINVAL, "Ax_func: Ax aliases v (cgmres.hpp:119-124)");
   return h->hook_Ax(out, v);
 }
 int cgmres_hip_gmres(cgmres_hip_handle h, void* x, const void* b) {
   NEED(h);
   if (!x || !b) return fail(CGMRES_HIP_EINVAL, "gmres: null pointer");
+  if (x == b) return fail(CGMRES_HIP_EINVAL, "gmres: x aliases b (matrix.hpp:76-81)");
   return h->hook_gmres(x, b);
 }
 int cgmres_hip_timer_start(cgmres_hip_handle h) {

@@ -206,6 +206,7 @@ struct CtxWg final : cgmres_hip_ctx {
     P.B = cfg.batch, P.dv = cfg.dv, P.kmax = cfg.k_max, P.L = L, P.fh_hbm = fh_hbm, P.lds_bytes = int(lds_bytes);
     P.Lp = L | 1, P.Lg = (L + 15) / 16 * 16, P.Lv = 16 * maxm, P.Pp = (np * (cfg.dv + 1)) | 1, P.Hp = pitch_H(cfg.k_max);
     P.h = T(cfg.h), P.dt = T(cfg.dt), P.tol = T(cfg.tol);
+    P.wave_dbg = ((cfg.flags & CGMRES_HIP_FLAG_WAVE_FRESH_TRIG) ? 1 : 0) | ((cfg.flags & CGMRES_HIP_FLAG_WAVE_SERIAL_SWEEPS) ? 2 : 0);
     P.inv_h = T(1.0) / P.h;
     P.one_m_zh = (1 - T(cfg.zeta) * P.h);
     const size_t B = cfg.batch, Lg = P.Lg;

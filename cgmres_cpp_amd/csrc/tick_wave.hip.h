@@ -63,14 +63,20 @@ struct WaveOps<PendulumDev<T>> : std::true_type {
   }
 };
 
-// LDS of one wave: the table of the serial sweeps, two control rows for them, the small Krylov arrays
+// LDS of one wave: the table of the serial sweeps and two control rows for them (nothing else lives in memory)
 template <class M, class T>
 struct WaveLds {
-  static constexpr int TAB_W = 2 * M::NX;  // per (sweep, stage): NX pairs (state component, trig value)
+  static constexpr int TAB_W = 2 * M::NX;  // per (sweep, stage): one pair (state component, trig value) per quad lane
   static __host__ __device__ int row_len(int dv) { return (dv * M::NU + 2) & ~1; }
-  static __host__ __device__ int pitch_H(int kmax) { return ((kmax * (kmax + 1)) / 2 + 3) & ~1; }
+  static __host__ __device__ int tab_len(int dv) { return (dv + 1) * TAB_W; }  // one sweep's table
+  // region A: the tables of sweeps #1 / #2 — dead once the solve starts — and, over them, the Krylov basis of the kernels
+  // that keep it in LDS ([vector][component][stage]); then the table of sweep #3 / of the serial fall-back, the two rows
+  static __host__ __device__ int region_a(int dv, int kmax) {
+    const int t = 2 * tab_len(dv), v = (kmax + 1) * M::NU * dv;
+    return ((t > v ? t : v) + 1) & ~1;
+  }
   static __host__ __device__ size_t count_T(int dv, int kmax) {
-    return size_t(3) * (dv + 1) * TAB_W + 2 * row_len(dv) + pitch_H(kmax) + (kmax + 2) + 3 * kmax + 6;
+    return size_t(region_a(dv, kmax)) + tab_len(dv) + 2 * row_len(dv) + 2;
   }
   static __host__ __device__ size_t bytes(int dv, int kmax, int waves) {
     return ((count_T(dv, kmax) * sizeof(T) + 15) & ~size_t(15)) * waves;
@@ -79,8 +85,36 @@ struct WaveLds {
 
 constexpr int WAVE_NEWTON_MAX = 8;
 
-template <class M, class T, int KM, int WPB>
-__global__ __launch_bounds__(64 * WPB) void tick_wave_kernel(WgParams<T> P) {
+// f(integral_constant<int, I>) for I = LO .. HI-1 (ascending) / HI-1 .. LO (descending): loops whose index must be a constant
+template <int LO, int HI, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (LO < HI) {
+    f(std::integral_constant<int, LO>{});
+    static_for<LO + 1, HI>(f);
+  }
+}
+template <int LO, int HI, class F>
+__device__ __forceinline__ void static_for_down(F&& f) {
+  if constexpr (LO < HI) {
+    f(std::integral_constant<int, HI - 1>{});
+    static_for_down<LO, HI - 1>(f);
+  }
+}
+
+// b in the lanes of `mask`, a elsewhere — as two v_cndmask on a scalar mask.  (Written as a ternary on the lane index the
+// compiler turned the choice into exec-mask branches inside the stage loop of the serial sweeps: ~30 cycles per taken branch.)
+__device__ __forceinline__ double lane_select(unsigned long long mask, double a, double b) {
+  int lo, hi;
+  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(lo) : "v"(__double2loint(a)), "v"(__double2loint(b)), "s"(mask));
+  asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(__double2hiint(a)), "v"(__double2hiint(b)), "s"(mask));
+  return __hiloint2double(hi, lo);
+}
+
+// VLDS: the Krylov basis lives in LDS instead of registers — the kernel then fits 256 registers and TWO waves share a SIMD
+// (batches beyond one controller per SIMD: their stalls overlap instead of running in rounds)
+template <class M, class T, int KM, int WPB, bool VLDS = false>
+__global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(VLDS ? 2 : 1, VLDS ? 2 : 1))) void tick_wave_kernel(
+    WgParams<T> P) {
   static_assert(WaveOps<M>::value, "model without wave scans");
   static_assert(std::is_same<T, double>::value, "the Newton thresholds are set for fp64");
   using W = WaveOps<M>;
@@ -95,13 +129,11 @@ __global__ __launch_bounds__(64 * WPB) void tick_wave_kernel(WgParams<T> P) {
   const int dv = P.dv, kmax = P.kmax, k1 = kmax + 1;
   // ---- LDS of this wave
   T* const base = reinterpret_cast<T*>(smem + size_t(wv) * Lds::bytes(dv, kmax, 1));
-  T* const tab = base;                                  // [3][dv+1][TAB_W]
-  T* const wrow = tab + 3 * (dv + 1) * Lds::TAB_W;      // [2][row_len]
+  T* const Vl = base;                                   // [kmax+1][NU][dv] (VLDS kernels), over the tables of sweeps 0, 1
+  T* const tab2 = base + Lds::region_a(dv, kmax);       // table of sweep 2
+  T* const wrow = tab2 + Lds::tab_len(dv);              // [2][row_len]
+  auto tab_of = [&](int q) { return q == 2 ? tab2 : base + q * Lds::tab_len(dv); };
   const int rlen = Lds::row_len(dv);
-  T* const Hi = wrow + 2 * rlen;                        // compact Hessenberg: column k = rows 0..k at k(k+1)/2
-  T* const rhoi = Hi + Lds::pitch_H(kmax);
-  T* const gi = rhoi + (kmax + 2);
-  auto hoff = [](int k) { return (k * (k + 1)) >> 1; };
   struct alignas(2 * sizeof(T)) WPair {
     T a, b;
   };
@@ -109,6 +141,7 @@ __global__ __launch_bounds__(64 * WPB) void tick_wave_kernel(WgParams<T> P) {
 
   typename M::template MathFor<false> mc;
   mc.init();
+  CGM_STAMP(0, -1);
   const bool in_hor = lane < dv;    // the lane has a stage with controls
   const bool in_traj = lane <= dv;  // ... or the terminal stage
   const int msrc = in_hor ? dv - 1 - lane : lane;  // mirrored lane of the costate scans (an involution on [0, dv))
@@ -173,13 +206,20 @@ __global__ __launch_bounds__(64 * WPB) void tick_wave_kernel(WgParams<T> P) {
     }
   };
 
-  // ---- serial state sweeps on DPP quads: quad q of `nq` runs sweep q; x(s), trig(s) -> tab[q][s]
+  // ---- serial state sweeps on DPP quads: quad q of [q_lo, q_hi) runs sweep q; x(s), trig(s) -> tab[q][s]
   //      q = 0: (U, x+hf, dtau_h)   q = 1: (U, x, dtau_0)   q = 2: (row 1 of wrow, x+hf, dtau_h)
+  //      Stage forms as in WgCtx::sweep_state: 0 = trig value ROTATED from the previous stage's through the exact angle
+  //      increment (PendulumDev::quad_stage_rot), 1 = fresh evaluation per stage, 2 = fresh with the library sin/cos.
+  //      A sweep whose increments leave the rotation's range is redone one form up, and the wave then stays with fresh
+  //      evaluations for ROT_HOLD sweeps (fast motion would otherwise pay for a failed rotation pass every tick).
+  constexpr int ROT_HOLD = 64;
+  int rot_hold = 0;
   auto serial_sweeps = [&](int q_lo, int q_hi, T dtau_h, T dtau_0) {
-    auto run = [&](auto slow_tag) -> bool {
-      constexpr bool SLOW = decltype(slow_tag)::value;
+    auto run = [&](auto mode_tag) -> int {  // 0 = done, 1 = an increment left the rotation range, 2 = argument beyond the fast trig range
+      constexpr int MODE = decltype(mode_tag)::value;
       const int q = lane >> 2, rho = lane & 3;
       T amax = T(0);
+      int zmax = 0;
       if (q >= q_lo && q < q_hi) {
         typename M::QuadLane Q;
         Q.init(rho, mc);
@@ -187,31 +227,66 @@ __global__ __launch_bounds__(64 * WPB) void tick_wave_kernel(WgParams<T> P) {
 #pragma unroll
         for (int c = 0; c < NX; ++c) x[c] = q == 1 ? xs[c] : xh[c];
         const T dtau = q == 1 ? dtau_0 : dtau_h, dtau1 = Q.sg * dtau;
-        const T* urow = wrow + (q == 2 ? rlen : 0);
-        WPair* pt = reinterpret_cast<WPair*>(tab + (q * (dv + 1)) * Lds::TAB_W) + rho;
-        T v = M::template quad_begin<SLOW>(x, Q, mc, &amax);
-        T ua = urow[0];
-        for (int s = 0; s < dv; ++s) {
-          // lane rho keeps component {0, 2, 1, 3}[rho] (x1 is sign-flipped on the d-lanes) next to its trig value
-          const T xc = rho == 0 ? x[0] : (rho == 1 ? x[2] : (rho == 2 ? x[1] : x[3]));
-          pt[s * NX] = {xc, v};
-          const T ub = urow[(s + 1) * NU];  // (the word after the last stage is the row's pad)
-          M::template quad_stage<SLOW>(x, v, ua, dtau, dtau1, Q, mc, &amax);
-          ua = ub;
+        const T* pu = wrow + (q == 2 ? rlen : 0);
+        WPair* pt = reinterpret_cast<WPair*>(tab_of(q)) + rho;
+        T v = M::template quad_begin<MODE == 2>(x, Q, mc, &amax);
+        T argp = M::quad_arg(x, Q);
+        T ua = pu[0];
+        // What the table keeps per stage: the trig value of every quad lane, x1 (lane 2: the d-lanes hold -x1) and x3
+        // (lane 3).  x0 and x2 obey a linear recurrence in u0 and are re-derived on the lanes by two scans (lin_states).
+        constexpr unsigned long long LANE3 = 0x8888888888888888ull;
+        auto stage = [&](int o, T u0) {
+          pt[o * NX] = {lane_select(LANE3, x[1], x[3]), v};
+          if constexpr (MODE == 0)
+            M::quad_stage_rot(x, v, argp, u0, dtau, dtau1, Q, mc, &zmax);
+          else
+            M::template quad_stage<MODE == 2>(x, v, u0, dtau, dtau1, Q, mc, &amax);
+        };
+        int s = 0;
+        for (; s + 4 <= dv; s += 4) {  // (the word after the last stage is the row's pad)
+          const T ub = pu[NU];
+          stage(0, ua);
+          const T uc = pu[2 * NU];
+          stage(1, ub);
+          const T ud = pu[3 * NU];
+          stage(2, uc);
+          ua = pu[4 * NU];
+          stage(3, ud);
+          pt += 4 * NX, pu += 4 * NU;
         }
-        const T xc = rho == 0 ? x[0] : (rho == 1 ? x[2] : (rho == 2 ? x[1] : x[3]));
-        pt[dv * NX] = {xc, v};
+        for (; s < dv; ++s) {
+          const T ub = pu[NU];
+          stage(0, ua);
+          ua = ub;
+          pt += NX, pu += NU;
+        }
+        pt[0] = {lane_select(LANE3, x[1], x[3]), v};
       }
-      return __any(M::quad_arg_bad(amax));
+      if (MODE == 0 && __any(M::quad_rot_bad(zmax))) return 1;
+      return __any(M::quad_arg_bad(amax)) ? 2 : 0;
     };
-    if (__builtin_expect(run(std::false_type{}), 0)) run(std::true_type{});  // arguments beyond the fast trig range
+    int st = rot_hold > 0 ? 1 : run(std::integral_constant<int, 0>{});
+    if (__builtin_expect(st == 1, 0)) {
+      if (rot_hold == 0) rot_hold = ROT_HOLD;
+      st = run(std::integral_constant<int, 1>{});
+    }
+    if (__builtin_expect(st == 2, 0)) run(std::integral_constant<int, 2>{});
+    if (rot_hold > 0) --rot_hold;
     wave_fence();
   };
   // the lane's stage of sweep q from the table: x[4] and {sin d, cos d, sin x1, cos x1}
-  auto read_tab = [&](int q, T* x, T* tr4) {
-    const WPair* pt = reinterpret_cast<const WPair*>(tab + (q * (dv + 1) + (in_traj ? lane : dv)) * Lds::TAB_W);
+  // x0(s), x2(s) of every lane's stage from the stage's control u0:  x2' = (1 - dtau As) x2 + dtau Bs u0,
+  // x0' = x0 + dtau x2  (model.hpp:38,40) — a geometric scan and a prefix sum
+  auto lin_states = [&](T u0, const T* xinit, T dtau, const GeoPowers<T>& G, T* x0, T* x2) {
+    const bool first = lane == 0;
+    const T e2 = (in_hor ? (dtau * M::Bs) * u0 : T(0)) + (first ? G.pw[0] * xinit[2] : T(0));
+    *x2 = wave_shift_up(scan_geo(e2, G), xinit[2]);
+    *x0 = wave_shift_up(scan_sum(dtau * *x2 + (first ? xinit[0] : T(0))), xinit[0]);
+  };
+  auto read_tab = [&](int q, T* x, T* tr4) {  // (x[0], x[2] are the caller's: lin_states)
+    const WPair* pt = reinterpret_cast<const WPair*>(tab_of(q) + (in_traj ? lane : dv) * Lds::TAB_W);
     const WPair e0 = pt[0], e1 = pt[1], e2 = pt[2], e3 = pt[3];
-    x[0] = e0.a, x[2] = e1.a, x[1] = e2.a, x[3] = e3.a;
+    x[1] = e2.a, x[3] = e3.a;
     tr4[0] = e0.b, tr4[1] = e1.b, tr4[2] = e2.b, tr4[3] = e3.b;
   };
 
@@ -224,10 +299,10 @@ __global__ __launch_bounds__(64 * WPB) void tick_wave_kernel(WgParams<T> P) {
 #pragma unroll
       for (int j = 0; j < NP; ++j) p[j] = in_traj ? src[j] : T(0);
     }
+    CGM_STAMP(0, 11);
     GeoPowers<T> Gh, G0;  // powers of 1 - dtau As for the geometric scans of this tick
     Gh.make(T(1) - dtau_h * M::As);
     G0.make(T(1) - dtau_0 * M::As);
-    for (int q = lane; q < Lds::pitch_H(kmax); q += 64) Hi[q] = T(0);  // the exported Hessenberg has no stale entries
     // ---- cgmres.hpp:83-85: x_dxh = x + h f(x, U_0)
     {
       T u0[NU], f[NX], tr[M::NC];
@@ -248,11 +323,14 @@ __global__ __launch_bounds__(64 * WPB) void tick_wave_kernel(WgParams<T> P) {
     }
     if (lane == 0) wrow[dv * NU] = T(0), wrow[rlen + dv * NU] = T(0);
     wave_fence();
+    CGM_STAMP(0, 0);
     serial_sweeps(0, 3, dtau_h, dtau_0);
+    CGM_STAMP(0, 1);
     T xb[NX], tb[4];  // base trajectory of this tick (sweep #1) on the lanes
     T bb[NU], ax0[NU];
     {
       read_tab(0, xb, tb);
+      lin_states(U[0], xh, dtau_h, Gh, &xb[0], &xb[2]);
       T phi[NU], dF, trig[3] = {tb[0], tb[1], tb[3]};
       backward(xb, trig, U, dtau_h, Gh, phi, &dF);
       finish(F_PLAIN, phi, dF, Fh);
@@ -260,6 +338,7 @@ __global__ __launch_bounds__(64 * WPB) void tick_wave_kernel(WgParams<T> P) {
     {
       T x[NX], t4[4];
       read_tab(1, x, t4);
+      lin_states(U[0], xs, dtau_0, G0, &x[0], &x[2]);
       T phi[NU], dF, trig[3] = {t4[0], t4[1], t4[3]};
       backward(x, trig, U, dtau_0, G0, phi, &dF);
       finish(F_RHS, phi, dF, bb);
@@ -269,30 +348,38 @@ __global__ __launch_bounds__(64 * WPB) void tick_wave_kernel(WgParams<T> P) {
       read_tab(2, x, t4);
 #pragma unroll
       for (int j = 0; j < NU; ++j) uu[j] = du[j] * P.h + U[j];
+      lin_states(uu[0], xh, dtau_h, Gh, &x[0], &x[2]);
       T phi[NU], dF, trig[3] = {t4[0], t4[1], t4[3]};
       backward(x, trig, uu, dtau_h, Gh, phi, &dF);
       finish(F_AX, phi, dF, ax0);
     }
 
+    CGM_STAMP(0, 2);
     // ---- Ax_func (cgmres.hpp:164-175) of the direction `dir`: Newton on the trajectory, from the base trajectory
     auto ax = [&](const T* dir, T* out) {
       T u[NU];
 #pragma unroll
       for (int j = 0; j < NU; ++j) u[j] = dir[j] * P.h + U[j];
-      // x2' = (1 - dtau As) x2 + dtau Bs u0;  x0' = x0 + dtau x2      (model.hpp:38,40)
-      const bool first = lane == 0;
-      const T e2 = (in_hor ? (dtau_h * M::Bs) * u[0] : T(0)) + (first ? Gh.pw[0] * xh[2] : T(0));
-      const T x2 = wave_shift_up(scan_geo(e2, Gh), xh[2]);
-      const T x0 = wave_shift_up(scan_sum(dtau_h * x2 + (first ? xh[0] : T(0))), xh[0]);
+      // A direction that the rounding of U + h*dir absorbs completely leaves the controls — and with them F — unchanged
+      // bit for bit: A*dir = 0 exactly, the reference's breakdown case (gmres.hpp:63-65).  Newton's fixed point agrees
+      // with the base trajectory only up to rounding, so that case is answered here.
+      if (__builtin_expect(!__any(in_hor && (u[0] != U[0] || u[1] != U[1] || u[2] != U[2])), 0)) {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) out[j] = T(0);
+        return;
+      }
+      T x0, x2;
+      lin_states(u[0], xh, dtau_h, Gh, &x0, &x2);
       const T Pq = M::A32 * x2 * x2, Qq = M::A32a * x2 - M::A32b * u[0];
       const T dx0 = x0 - xb[0];
       T y1 = xb[1], y3 = xb[3];
+      CGM_STAMP(0, 3);
       T sd = tb[0], cd = tb[1], s1 = tb[2], c1 = tb[3];
       bool converged = false;
       const T rmax = T(0.9) * sqrt_t<T>(T(decltype(mc)::rot_zmax));
-      for (int it = 0; it < WAVE_NEWTON_MAX; ++it) {
+      for (int it = 0; it < ((P.wave_dbg & 2) ? 0 : WAVE_NEWTON_MAX); ++it) {
         const T d1 = y1 - xb[1], dd = dx0 - d1;
-        if (__builtin_expect(__any(in_traj && (!(abs_t(dd) <= rmax) || !(abs_t(d1) <= rmax))), 0)) {
+        if (__builtin_expect((P.wave_dbg & 1) || __any(in_traj && (!(abs_t(dd) <= rmax) || !(abs_t(d1) <= rmax))), 0)) {
           mc.sincos_pair(x0 - y1, y1, &sd, &cd, &s1, &c1);  // far from the base trajectory: fresh evaluation
         } else {
           W::rotate(tb[0], tb[1], dd, &sd, &cd, mc);
@@ -307,6 +394,7 @@ __global__ __launch_bounds__(64 * WPB) void tick_wave_kernel(WgParams<T> P) {
         T D[4] = {T(0), dtau_h, dtau_h * wave_shift_up(J1, T(0)), -dtau_h * M::C22};
         scan_aff2(D, c);
         y1 += c[0], y3 += c[1];
+        CGM_STAMP(0, 4);
         const T th = T(1e-10);
         if (!__any(in_traj && (abs_t(c[0]) > th * (T(1) + abs_t(y1)) || abs_t(c[1]) > th * (T(1) + abs_t(y3))))) {
           // the correction is below the square root of the rounding level: trig values to first order, done
@@ -327,17 +415,53 @@ __global__ __launch_bounds__(64 * WPB) void tick_wave_kernel(WgParams<T> P) {
         wave_fence();
         serial_sweeps(2, 3, dtau_h, dtau_0);
         T t4[4];
-        read_tab(2, x, t4);
+        read_tab(2, x, t4);  // (x[0], x[2] stay the scans' values)
         trig[0] = t4[0], trig[1] = t4[1], trig[2] = t4[3];
       }
       T phi[NU], dF;
+      CGM_STAMP(0, 12);
       backward(x, trig, u, dtau_h, Gh, phi, &dF);
       finish(F_AX, phi, dF, out);
+      CGM_STAMP(0, 5);
     };
 
-    // ---- Gmres::gmres (gmres.hpp:28-112), basis in registers
-    T V[KM + 1][NU];
+    // ---- Gmres::gmres (gmres.hpp:28-112): basis, Hessenberg, reflectors and residual vector all in registers.
+    //      H is kept by ROWS over the lanes — lane j holds H(j, c) in Hrow[c] — and rho_e likewise (lane j holds
+    //      rho_e[j] in `e`): the triangular solve at the end (gmres.hpp:100-107) then needs no memory at all.  The column
+    //      of the running iteration and the reflectors are wave-uniform values.
+    T V[VLDS ? 1 : KM + 1][NU];
+    auto put_v = [&](auto qc, const T* v) {  // basis vector q <- v
+      constexpr int q = decltype(qc)::value;
+      if constexpr (VLDS) {
+        if (in_hor) {
+#pragma unroll
+          for (int j = 0; j < NU; ++j) Vl[(q * NU + j) * dv + lane] = v[j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) V[q][j] = v[j];
+      }
+    };
+    auto get_v = [&](auto qc, T* v) {
+      constexpr int q = decltype(qc)::value;
+      if constexpr (VLDS) {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) v[j] = Vl[(q * NU + j) * dv + (in_hor ? lane : 0)];
+        if (!in_hor) {
+#pragma unroll
+          for (int j = 0; j < NU; ++j) v[j] = T(0);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) v[j] = V[q][j];
+      }
+    };
     T vcur[NU], w[NU];
+    T Hrow[KM];
+    T gr0 = T(0), gr1 = T(0), gr2 = T(0);  // reflector i = (gr0, gr1, gr2) of LANE i (gmres.hpp:81-83)
+    T e = T(0), ek = T(0), hsub = T(0);
+#pragma unroll
+    for (int c = 0; c < KM; ++c) Hrow[c] = T(0);
     bool active = true;
     reason = 0, n_ax = 0, ksolve = 0;
     auto dot = [&](const T* a, const T* c) {
@@ -350,100 +474,126 @@ __global__ __launch_bounds__(64 * WPB) void tick_wave_kernel(WgParams<T> P) {
 #pragma unroll
       for (int j = 0; j < NU; ++j) vcur[j] = bb[j] - ax0[j];  // gmres.hpp:33-34
       const T rho0 = sqrt_t<T>(dot(vcur, vcur));               // :37
-      if (lane == 0) rhoi[0] = rho0;
+      ek = rho0;
+      e = lane == 0 ? rho0 : T(0);
       // (decisions go through __any: wave-uniform by construction, and the compiler then keeps them in scalar registers)
       if (__any(!finite_t(rho0))) active = false, reason = 4;         // CGMRES_HIP_EXIT_NONFINITE
       if (active && __any(rho0 < P.tol)) active = false, reason = 2;  // :39-41
       if (active) {
         const T inv = T(1.0) / rho0;  // :44
 #pragma unroll
-        for (int j = 0; j < NU; ++j) vcur[j] = vcur[j] * inv, V[0][j] = vcur[j];
+        for (int j = 0; j < NU; ++j) vcur[j] = vcur[j] * inv;
+        put_v(std::integral_constant<int, 0>{}, vcur);
       }
     }
+    CGM_STAMP(0, 9);
     int nv = active ? 1 : 0;  // basis vectors stored
-    int k = 0;
-    for (; active && k < kmax; ++k) {  // gmres.hpp:46
-      ax(vcur, w);                     // :48
-      n_ax = k + 1;
-      T* Hk = Hi + hoff(k);
-      // modified Gram-Schmidt (:52-58), in order, one static instance per k (register-resident basis)
-      auto rounds = [&](auto kc) {
-        constexpr int K = decltype(kc)::value;
+    // One Arnoldi iteration after the mat-vec, one static instance per k.  Returns 0 (go on), 1 (converged, :93-95),
+    // 3 (breakdown, :63-65) or 4 (non-finite norm).
+    auto iteration = [&](auto kc) -> int {
+      constexpr int K = decltype(kc)::value;
+      T hc[K + 1];
+      T hraw = T(0);  // row `lane` of the column as Gram-Schmidt leaves it (what a breakdown exports)
+      // modified Gram-Schmidt (:52-58), in order
+      T vi[NU], vn[NU];
+      get_v(std::integral_constant<int, 0>{}, vi);
+      static_for<0, K + 1>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (i < K) get_v(std::integral_constant<int, i + 1>{}, vn);  // (LDS: requested a round ahead)
+        const T hik = dot(vi, w);
 #pragma unroll
-        for (int i = 0; i <= K; ++i) {
-          const T hik = dot(V[i], w);
+        for (int j = 0; j < NU; ++j) w[j] = fma_t(-hik, vi[j], w[j]);
+        hc[i] = hik;
+        hraw = lane == i ? hik : hraw;
 #pragma unroll
-          for (int j = 0; j < NU; ++j) w[j] = fma_t(-hik, V[i][j], w[j]);
-          if (lane == 0) Hk[i] = hik;
-        }
-      };
-      switch (k) {
-#define CGM_WCASE(n)                                    \
-  case n:                                               \
-    if constexpr (n < KM) rounds(std::integral_constant<int, n>{}); \
-    break;
-        CGM_WCASE(0) CGM_WCASE(1) CGM_WCASE(2) CGM_WCASE(3) CGM_WCASE(4) CGM_WCASE(5) CGM_WCASE(6) CGM_WCASE(7)
-        CGM_WCASE(8) CGM_WCASE(9) CGM_WCASE(10) CGM_WCASE(11) CGM_WCASE(12) CGM_WCASE(13) CGM_WCASE(14) CGM_WCASE(15)
-        default: break;
-      }
+        for (int j = 0; j < NU; ++j) vi[j] = vn[j];
+      });
+      CGM_STAMP(0, 6);
       const T hn = sqrt_t<T>(dot(w, w));  // :60
       if (__any(abs_t(hn) < T(DBL_EPSILON) || !finite_t(hn))) {  // :63-65 breakdown: x untouched; non-finite: x <- NaN below
-        reason = __any(!finite_t(hn)) ? 4 : 3;
-        if (lane == 0) rhoi[kmax + 1] = hn;  // (exported as h(k+1,k) of the column that broke down)
-        active = false;
-        break;
+        hsub = hn;  // (exported as h(k+1,k) of the column that broke down, before any rotation)
+        Hrow[K] = hraw;
+        return __any(!finite_t(hn)) ? 4 : 3;
       }
       const T inv = T(1.0) / hn;  // :67
 #pragma unroll
       for (int j = 0; j < NU; ++j) vcur[j] = w[j] * inv;
-      switch (k) {
-#define CGM_WSTORE(n)                                  \
-  case n:                                              \
-    if constexpr (n < KM) {                            \
-      for (int j = 0; j < NU; ++j) V[n + 1][j] = vcur[j]; \
-    }                                                  \
-    break;
-        CGM_WSTORE(0) CGM_WSTORE(1) CGM_WSTORE(2) CGM_WSTORE(3) CGM_WSTORE(4) CGM_WSTORE(5) CGM_WSTORE(6) CGM_WSTORE(7)
-        CGM_WSTORE(8) CGM_WSTORE(9) CGM_WSTORE(10) CGM_WSTORE(11) CGM_WSTORE(12) CGM_WSTORE(13) CGM_WSTORE(14)
-        CGM_WSTORE(15)
-        default: break;
+      put_v(std::integral_constant<int, K + 1>{}, vcur);
+      nv = K + 2;
+      CGM_STAMP(0, 7);
+      // Hessenberg column K: stored reflectors, new reflector, residual rotation (:71-90)
+      // (row i of the rotated column goes to lane i as it is produced)
+      T a = hc[0], hrot = T(0);
+#pragma unroll
+      for (int i = 0; i < K; ++i) {
+        const T c = hc[i + 1];
+        const T q0 = wave_bcast(gr0, i), q1 = wave_bcast(gr1, i), q2 = wave_bcast(gr2, i);
+        const T beta = (q0 * a + q1 * c) * q2;
+        hrot = lane == i ? a - beta * q0 : hrot;
+        a = c - beta * q1;
       }
-      nv = k + 2;
-      // Hessenberg column k: stored reflectors, new reflector, residual rotation (:71-90) — wave-uniform scalar work on
-      // the small arrays in LDS (every lane computes, lane 0 stores)
-      wave_fence();
-      const T en = WgCtx<M, T, 16, 10>::hess_column(Hi, gi, rhoi, k, hn, lane == 0);
-      wave_fence();
-      if (__any(abs_t(en) < P.tol)) {  // :93-95 — converged: column k is NOT used by the solve
-        reason = 1, ksolve = k;
+      const T sigma = -(a < T(0.0) ? T(-1.0) : T(1.0)) * sqrt_t<T>(a * a + hn * hn);
+      const T g0 = a - sigma, g1 = hn;
+      const T g2 = T(2.0) / (g0 * g0 + g1 * g1);
+      gr0 = lane == K ? g0 : gr0, gr1 = lane == K ? g1 : gr1, gr2 = lane == K ? g2 : gr2;
+      hrot = lane == K ? sigma : hrot;
+      const T beta = g0 * ek * g2;
+      const T en = -beta * g1;
+      e = lane == K ? ek - beta * g0 : (lane == K + 1 ? en : e);
+      ek = en;
+      Hrow[K] = hrot;
+      CGM_STAMP(0, 8);
+      return __any(abs_t(en) < P.tol) ? 1 : 0;
+    };
+    int k = 0;
+    for (; active && k < kmax; ++k) {  // gmres.hpp:46
+      ax(vcur, w);                     // :48
+      n_ax = k + 1;
+      int st = 0;
+      switch (k) {
+#define CGM_WCASE(n)                                                      \
+  case n:                                                                 \
+    if constexpr (n < KM) st = iteration(std::integral_constant<int, n>{}); \
+    break;
+        CGM_WCASE(0) CGM_WCASE(1) CGM_WCASE(2) CGM_WCASE(3) CGM_WCASE(4) CGM_WCASE(5) CGM_WCASE(6) CGM_WCASE(7)
+        CGM_WCASE(8) CGM_WCASE(9) CGM_WCASE(10) CGM_WCASE(11) CGM_WCASE(12) CGM_WCASE(13) CGM_WCASE(14) CGM_WCASE(15)
+        default: break;
+#undef CGM_WCASE
+      }
+      if (st != 0) {
+        reason = st;
+        if (st == 1) ksolve = k;  // converged: column k is NOT used by the solve
         active = false;
         break;
       }
     }
+    CGM_STAMP(0, 13);
     if (reason == 0) ksolve = kmax;  // natural exit: every column is used
     if (reason <= 1) {
-      // back substitution (gmres.hpp:100-107) over the lanes: lane j owns e_j (see WgCtx::gmres)
+      // back substitution (gmres.hpp:100-107), column-oriented over the lanes: step i (descending) turns e_i into
+      // y_i = e_i / H_ii and every lane j < i subtracts H(j,i) y_i — for a fixed j in the reference's order
       const int ks = ksolve;
-      T e = lane < ks ? rhoi[lane] : T(0);
-      for (int i = ks - 1; i >= 0; --i) {
-        const T hii = Hi[hoff(i) + i], hji = Hi[hoff(i) + (lane < i ? lane : i)];
-        const T y = e / hii;  // meaningful in lane i
-        const T yi = wave_bcast(y, i);
-        e = lane < i ? e - hji * yi : (lane == i ? y : e);
+#pragma unroll
+      for (int i = KM - 1; i >= 0; --i) {
+        if (i < ks) {
+          const T yi = wave_bcast(e, i) / wave_bcast(Hrow[i], i);
+          e = lane < i ? fma_t(-Hrow[i], yi, e) : (lane == i ? yi : e);
+        }
       }
-      if (lane < ks) rhoi[lane] = e;
       // x += V[:, 0:ks] y (gmres.hpp:110-111), accumulated j-ascending from 0
       T acc[NU];
 #pragma unroll
       for (int j = 0; j < NU; ++j) acc[j] = T(0);
-#pragma unroll
-      for (int q = 0; q < KM; ++q) {
+      static_for<0, KM>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
         if (q < ks) {
           const T yq = wave_bcast(e, q);
+          T vq[NU];
+          get_v(qc, vq);
 #pragma unroll
-          for (int j = 0; j < NU; ++j) acc[j] = fma_t(V[q][j], yq, acc[j]);
+          for (int j = 0; j < NU; ++j) acc[j] = fma_t(vq[j], yq, acc[j]);
         }
-      }
+      });
 #pragma unroll
       for (int j = 0; j < NU; ++j) du[j] = du[j] + acc[j];
     }
@@ -451,6 +601,7 @@ __global__ __launch_bounds__(64 * WPB) void tick_wave_kernel(WgParams<T> P) {
 #pragma unroll
       for (int j = 0; j < NU; ++j) du[j] = in_hor ? quiet_nan<T>() : T(0);
     }
+    CGM_STAMP(0, 10);
     // ---- U += dUdt*dt, u = U[0:dim_u]  (cgmres.hpp:102-109)
 #pragma unroll
     for (int j = 0; j < NU; ++j) U[j] = U[j] + du[j] * P.dt;
@@ -469,30 +620,35 @@ __global__ __launch_bounds__(64 * WPB) void tick_wave_kernel(WgParams<T> P) {
       if (lane < NX) P.xdxh[size_t(b) * NX + lane] = lane == 0 ? xh[0] : (lane == 1 ? xh[1] : (lane == 2 ? xh[2] : xh[3]));
       // status + small Krylov arrays (the layout of WgCtx::store_status) + the basis rows in the wg mapping's
       // pair-interleaved form (ctx_wg get_krylov undoes it)
-      wave_fence();
       const int ks_all = k1 * k1 + k1 + 3 * kmax;
       T* dst = P.kry + size_t(b) * ks_all;
-      for (int q = lane; q < k1 * k1; q += 64) {
+      for (int q = lane; q < k1 * k1; q += 64) {  // everything outside the upper triangle of the executed columns
         const int col = q / k1, row = q - col * k1;
-        T v = (col < kmax && row <= col) ? Hi[hoff(col) + row] : T(0);
-        if (row == col + 1 && col + 1 == n_ax && reason == 3) v = rhoi[kmax + 1];
-        dst[q] = v;
+        if (row > col || col >= kmax) dst[q] = (row == col + 1 && col + 1 == n_ax && reason == 3) ? hsub : T(0);
       }
-      for (int q = lane; q < k1; q += 64) dst[k1 * k1 + q] = rhoi[q];
-      for (int q = lane; q < 3 * kmax; q += 64) dst[k1 * k1 + k1 + q] = gi[q];
+#pragma unroll
+      for (int c = 0; c < KM; ++c)
+        if (c < kmax && lane <= c) dst[c * k1 + lane] = Hrow[c];
+      if (lane < k1) dst[k1 * k1 + lane] = e;
+      if (lane < kmax) {
+        T* gd = dst + k1 * k1 + k1 + 3 * lane;
+        gd[0] = gr0, gd[1] = gr1, gd[2] = gr2;
+      }
       if (lane == 0) P.n_ax[b] = n_ax, P.reason[b] = reason;
       if (in_hor) {
-#pragma unroll
-        for (int q = 0; q <= KM; ++q) {
+        static_for<0, KM + 1>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
           if (q < nv) {
             T* row = P.V + (size_t(b) * k1 + q) * P.Lv;
+            T vq[NU];
+            get_v(qc, vq);
 #pragma unroll
             for (int j = 0; j < NU; ++j) {
-              const int e = lane * NU + j, rr = e & 15, m = e >> 4;
-              row[(m >> 1) * 32 + 2 * rr + (m & 1)] = V[q][j];
+              const int el = lane * NU + j, rr = el & 15, m = el >> 4;
+              row[(m >> 1) * 32 + 2 * rr + (m & 1)] = vq[j];
             }
           }
-        }
+        });
       }
     }
     if (P.x_next) {  // plant step of the example main loop (<example>/main.cpp:71-73)
@@ -504,6 +660,10 @@ __global__ __launch_bounds__(64 * WPB) void tick_wave_kernel(WgParams<T> P) {
         P.x_next[size_t(b) * NX + lane] = lane == 0 ? xs[0] : (lane == 1 ? xs[1] : (lane == 2 ? xs[2] : xs[3]));
     }
   }
+  CGM_STAMP(0, 11);
+#ifdef CGM_STAMPS
+  cgm_stamp_flush();
+#endif
 }
 
 }  // namespace cgm

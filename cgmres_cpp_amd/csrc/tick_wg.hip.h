@@ -51,8 +51,10 @@ enum WgMode { WG_TICK = 0, WG_HOOK_F = 1, WG_HOOK_PREPARE = 2, WG_HOOK_AX = 3, W
 template <class T>
 struct WgParams {
   int B, dv, kmax, L, Lp, Lg, Lv, Pp, Hp, fh_hbm, lds_bytes;  // fh_hbm: F(U,x+hf,t+h) is kept in HBM only (P.Fh), see WgLds
+  int wave_dbg;   // wave mapping (tick_wave.hip.h): 1 = Newton with fresh sin/cos, 2 = serial state sweep in every mat-vec
   int cs_chunks;  // chunks of the two-pass costate sweep (WgCtx::sweep_costate_2pass): 3 or 4, what the LDS budget allows
-   // Lp/Pp/Hp: odd LDS row pitches (Hp: the COMPACT Hessenberg, column k = k+2 entries at offset k(k+3)/2);
+   // Lp/Pp/Hp: odd LDS row pitches (Hp: the COMPACT Hessenberg, column k = rows 0..k at offset k(k+1)/2; h(k+1,k) of the
+   // column in progress lives in WgLds::hsub);
    // Lg: global row pitch (multiple of 16); Lv = 16*MAXM: pitch of the Krylov rows (pads kept zero, no guards)
   T h, dt, tol, inv_h, one_m_zh, dtau_h, dtau_0;
   // closed loop on the device: up to CGM_FUSE_MAX consecutive ticks per launch, the controller state (U in LDS, dUdt
@@ -1514,10 +1516,7 @@ struct WgCtx {
     // Gram-Schmidt rounds are bounded by the CU's 64 B/clk vector-memory path, not by issue.  The ring then serves the
     // rows from NKEEP on.  Pays for itself only where registers are left: the one-workgroup-per-CU kernels with short
     // vectors, with the solution vector parked in HBM for the duration of the loop like the long-vector kernels do.
-#ifndef CGM_AB_NKEEP
-#define CGM_AB_NKEEP 2
-#endif
-    constexpr int NKEEP = (!LEAN && MAXM <= 10) ? CGM_AB_NKEEP : 0;
+    constexpr int NKEEP = (!LEAN && MAXM <= 10) ? 2 : 0;
     T vkeep[NKEEP > 0 ? NKEEP : 1][MAXM];
     // workgroup-uniform; longer bases use the plain streaming loop.  So does the lean plan: with 256 registers per wave the
     // twelve straight-line copies of the rounds push everything that lives across them (U, the sweep constants) into

@@ -71,7 +71,11 @@ enum {
   CGMRES_HIP_FLAG_IPW8 = 2,           /* wg mapping: 8 instead of 16 instances per workgroup where that fits */
   CGMRES_HIP_FLAG_NO_BINNING = 4,     /* closed loop: keep instances in caller order inside the workgroups (no k-binning) */
   CGMRES_HIP_FLAG_TWO_PASS_COSTATE = 8, /* wg mapping: the two-pass chunk-parallel costate sweep also where the LDS-scratch form fits */
-  CGMRES_HIP_FLAG_NO_WAVE = 16         /* library's choice of mapping: never the wave mapping (small batches stay on wg) */
+  CGMRES_HIP_FLAG_NO_WAVE = 16,        /* library's choice of mapping: never the wave mapping (small batches stay on wg) */
+  CGMRES_HIP_FLAG_WAVE_FRESH_TRIG = 32, /* wave mapping: every Newton iteration evaluates sin/cos afresh (the path taken when a
+                                          trajectory strays from the base trajectory by more than the rotation range) */
+  CGMRES_HIP_FLAG_WAVE_SERIAL_SWEEPS = 64 /* wave mapping: every mat-vec takes the serial state sweep (the fall-back of a Newton
+                                          iteration that does not settle) */
 };
 
 /* cgmres_hip_closed_loop_device advances up to this many consecutive ticks per kernel launch (the controller

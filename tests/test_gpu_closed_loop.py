@@ -30,6 +30,10 @@ CASES = {
     "pendulum_B4096_lean_fixedk": (0, 50, 10, 0.0, "f64", 4096, 3),
     "msd_B4096_lean": (1, 50, 10, 1e-6, "f64", 4096, 3),            # members, MultipleController's mapping
     "semiactive_B8192_lean": (2, 50, 10, 1e-6, "f64", 8192, 3),
+    "pendulum_B256_wave": (0, 50, 10, 1e-6, "f64", 256, 4),         # BASELINE configs[1] on the latency mapping (one wave per controller)
+    "pendulum_B512_wave_fixedk": (0, 50, 10, 0.0, "f64", 512, 4),   # the per-GPU shard of the headline batch at 8 GPUs
+    "pendulum_B4096_wave": (0, 50, 10, 1e-6, "f64", 4096, 4),       # the wave mapping oversubscribed (several waves per SIMD / rounds)
+    "pendulum_dv25_k5_B67_wave": (0, 25, 5, 1e-6, "f64", 67, 4),    # shipped sizes, ragged batch
     "pendulum_B200_lane": (0, 50, 10, 1e-6, "f64", 200, 1),         # the lane mapping: one tick per launch
     "msd_dv20_k5_B33": (1, 20, 5, 1e-6, "f64", 33, 2),              # ragged batch, shipped-size MSD (IPW rows unused)
 }

@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 
 U_TOL = 1e-9
 DUDT_REL = 1e-7
-VARIANTS = [2, 1, 3]  # 2 = "wg" (default mapping), 1 = "lane" (reference statement order), 3 = "wg-lean" (two workgroups per CU)
+VARIANTS = [2, 1, 3, 4]  # 2 = "wg" (default mapping), 1 = "lane" (reference statement order), 3 = "wg-lean" (two workgroups per CU),
+#                          4 = "wave" (one wavefront per controller: the latency mapping; pendulum fp64, dv <= 63, k_max <= 10)
 
 
 def dudt_close(a, b, rel=DUDT_REL):
@@ -22,10 +23,20 @@ def dudt_close(a, b, rel=DUDT_REL):
     return float(np.max(np.abs(a - b))) <= rel * scale
 
 
+def new_batch(*a, **kw):
+    """cg.CgmresBatch; a size / model the wave mapping does not serve skips the test case."""
+    try:
+        return cg.CgmresBatch(*a, **kw)
+    except cg.CgmresHipError as e:
+        if kw.get("variant") == 4 and "wave mapping" in str(e):
+            pytest.skip("the wave mapping does not cover this model / dtype / size")
+        raise
+
+
 def make_batch(case, batch, variant=0, tol=None):
     try:
-        return cg.CgmresBatch(case["model"], batch=batch, dv=case["dv"], k_max=case["kmax"],
-                              tol=case["tol"] if tol is None else tol, dtype=case["dtype"], variant=variant)
+        return new_batch(case["model"], batch=batch, dv=case["dv"], k_max=case["kmax"],
+                         tol=case["tol"] if tol is None else tol, dtype=case["dtype"], variant=variant)
     except cg.CgmresHipError as e:
         if variant == 3 and "wg-lean mapping" in str(e):  # sizes beyond half a CU's LDS (e.g. fp64 with dim_u*dv = 300, k = 20)
             pytest.skip("lean LDS plan does not cover these sizes")
@@ -205,7 +216,7 @@ def test_seeded_batch_vs_oracle(orc, model, dv, kmax, tol, B, ticks, variant):
     """Closed loop of a seeded perturbed batch; every tick is compared instance by instance with the
     oracle, then the oracle's x is adopted (teacher forcing) so both sides always see identical inputs."""
     x0, u0, p = orc.batch_scenario(model, B)
-    c = cg.CgmresBatch(model, batch=B, dv=dv, k_max=kmax, tol=tol, variant=variant)
+    c = new_batch(model, batch=B, dv=dv, k_max=kmax, tol=tol, variant=variant)
     c.set_ptau_repeat(p)
     c.init_u0(u0)
     c.init_u0_newton(u0, x0, p, 10)
@@ -373,7 +384,7 @@ def test_large_angles_take_the_library_trig_path(orc, variant):
     x0[5, 1] -= 30000 * two_pi   # both angles out of range
     x0[17, 0] += 15915 * two_pi  # just below 1e5: crosses the cut-over only if the sweep moves it
     x0[17, 1] += 15915 * two_pi
-    c = cg.CgmresBatch(model, batch=B, dv=dv, k_max=kmax, tol=tol, variant=variant)
+    c = new_batch(model, batch=B, dv=dv, k_max=kmax, tol=tol, variant=variant)
     c.set_ptau_repeat(p)
     c.init_u0(u0)
     c.init_u0_newton(u0, x0, p, 10)
@@ -411,7 +422,7 @@ def test_fast_angular_rates_leave_the_rotation_range(orc, variant):
     x0[9, 3] = 25.0                      # x1 alone moves 0.1 per stage
     x0[21, 2], x0[21, 3] = -12.0, 9.0    # 0.08: beyond the range as well
     x0[33, 2] = 8.0                      # 0.03: stays inside
-    c = cg.CgmresBatch(model, batch=B, dv=dv, k_max=kmax, tol=tol, variant=variant)
+    c = new_batch(model, batch=B, dv=dv, k_max=kmax, tol=tol, variant=variant)
     c.set_ptau_repeat(p)
     c.init_u0(u0)
     c.init_u0_newton(u0, x0, p, 10)
@@ -512,7 +523,7 @@ def test_status_exit_paths(orc, variant):
     x0, u0, p = orc.batch_scenario(2, B)
 
     def both(tol, u_init=None, x0=x0):
-        c = cg.CgmresBatch("semiactive", batch=B, dv=dv, k_max=km, tol=tol, variant=variant)
+        c = new_batch("semiactive", batch=B, dv=dv, k_max=km, tol=tol, variant=variant)
         ui = u0 if u_init is None else u_init
         c.init_u0(ui)
         refs = []
@@ -586,7 +597,7 @@ def test_nonfinite_state_is_flagged_per_instance(orc, variant):
     x = x0.copy()
     for i, v in bad.items():
         x[i, i % 2] = v
-    c = cg.CgmresBatch(model, batch=B, dv=dv, k_max=km, tol=1e-6, variant=variant)
+    c = new_batch(model, batch=B, dv=dv, k_max=km, tol=1e-6, variant=variant)
     c.set_ptau_repeat(p)
     c.init_u0(u0)
     c.init_u0_newton(u0, x0, p, 10)
@@ -617,7 +628,7 @@ def test_ax_func_after_control(orc, model, dv, kmax, variant):
     mappings must agree with the oracle (MSD at dv = 50 runs the fh_hbm plan of the wg mapping)."""
     B = 19
     x0, u0, p = orc.batch_scenario(model, B)
-    c = cg.CgmresBatch(model, batch=B, dv=dv, k_max=kmax, variant=variant)
+    c = new_batch(model, batch=B, dv=dv, k_max=kmax, variant=variant)
     c.set_ptau_repeat(p)
     c.init_u0(u0)
     c.init_u0_newton(u0, x0, p, 10)

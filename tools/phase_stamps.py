@@ -39,7 +39,7 @@ B, DV, KM = opt("batch", 4096), opt("dv", 50), opt("kmax", 10)
 NAME = "pendulum" if MODEL == "pendulum32" else MODEL
 DT = "f32" if MODEL == "pendulum32" else "f64"
 x0, u0, p = scenarios.batch(NAME, B)
-c = cg.CgmresBatch(NAME, batch=B, dv=DV, k_max=KM, tol=0.0, dtype=DT)
+c = cg.CgmresBatch(NAME, batch=B, dv=DV, k_max=KM, tol=0.0, dtype=DT, variant=opt("variant", 0))
 print("variant", c.variant, c.variant_name, "B", B, "dv", DV, "kmax", KM, DT)
 x0, u0 = x0.astype(c.np_dtype), u0.astype(c.np_dtype)
 c.set_ptau_repeat(p); c.init_u0(u0); c.init_u0_newton(u0, x0, p, 10)
@@ -56,6 +56,11 @@ names = {14: "loop top: before barrier_or", 15: "barrier_or (drains V row store)
          16: "costate A: four chunks side by side (record store when 18-20 are stamped)", 17: "costate: barrier",
          6: "sweep phase 3 (costate; B: boundaries + combine if chunk-parallel)", 7: "MGS rounds", 8: "norm+normalise+store",
          9: "Hessenberg scalar", 10: "loop exit barrier", 11: "back-subst", 12: "x update (V*y)", 13: "epilogue"}
+if c.variant == 4:  # the wave mapping's own stamp ids (tick_wave.hip.h)
+    names = {11: "tick top / epilogue tail", 0: "x+hf, control rows", 1: "serial state sweeps (3 quads)", 2: "preamble: 3 x costate scans",
+             3: "ax: x0/x2 scans", 4: "ax: Newton iterations (visits = iterations)", 12: "ax: after Newton (first-order fix)", 5: "ax: costate scans + dH/du",
+             9: "r0", 6: "MGS rounds", 7: "norm+normalise+store", 8: "Hessenberg scalar", 13: "loop exit",
+             10: "back-subst + x update"}
 tot = out[29]; wall = out[28]
 print(f"ticks {N}: shader cycles/tick {tot/N:.0f}, wall {wall/N/100:.1f} us/tick -> clock {tot/wall*100/1e3:.2f} GHz")
 for k, n in names.items():
