@@ -38,11 +38,30 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X_MICROARCH.md: vector fp64 (256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz)
 MODEL, MODEL_ID, DV, KMAX = "pendulum", 0, 50, 10
 DIM_X, DIM_U, DIM_P = 4, 3, 2
 GLOBAL_BATCH = 4096
 # rocprofv3 PMC summary of this same command (tools/profile_bench.sh + tools/summarise_profile.py), newest first
 ISSUE_MODELS = [os.path.join(ROOT, "profiles", n) for n in ("r03_issue_model.json", "r02_issue_model.json")]
+KERNEL_OF_VARIANT = {1: "tick_lane_kernel", 2: "tick_wg_kernel", 3: "tick_wg_kernel", 4: "tick_wave_kernel"}
+
+
+def algorithmic_flops(k, L=DIM_U * DV):
+    """SURVEY.md §8(d), secondary (VALU) view: fp64 operations of one instance-tick, transcendentals not counted:
+    (3+k) dv (phi + 16) + (3+k) 4L + 4L k(k+1)/2 + 3Lk + (k+4) 2L with phi_pendulum = 95."""
+    return (3 + k) * DV * (95 + 16) + (3 + k) * 4 * L + 4 * L * k * (k + 1) // 2 + 3 * L * k + (k + 4) * 2 * L
+
+
+def library_hash():
+    """sha256 (16 hex digits) of the libcgmres_hip.so this process loads: profiles carry the hash of the library they
+    were taken with (tools/summarise_profile.py), and a counter figure is only quoted next to a timing of the same build."""
+    import hashlib
+    import cgmres_cpp_amd as cg
+    try:
+        return hashlib.sha256(open(cg.lib_path(), "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
 
 
 def algorithmic_bytes(k, L=DIM_U * DV, scalar=8):
@@ -51,15 +70,17 @@ def algorithmic_bytes(k, L=DIM_U * DV, scalar=8):
     return scalar * (L * (8 + 6 * k + k * (k - 1) // 2) + (3 + k) * (DIM_P * (DV + 1) + DIM_X) + DIM_U)
 
 
-def cpu_baseline(batch, tol, warm, seconds_budget):
+def cpu_baseline(batch, tol, warm, seconds_budget, n_all=None):
     """The oracle (CPU restatement, bit-exact with the reference) on this host's cores: same seeded inputs, closed
-    loop.  Two legs: all hardware threads available to the process on the whole batch, and ONE
-    thread on the first 256 instances of the same batch."""
+    loop.  Two legs: all hardware threads available to the process on the whole batch (or, for a long
+    warm-up, on its first `n_all` instances — instances are independent, the rate per instance is what is measured),
+    and ONE thread on the first 256 instances of the same batch."""
     from oracle import orc
     if not os.path.exists(orc.ORACLE_SO):
         orc.build(ref=False)
     threads = len(os.sched_getaffinity(0))
     x0, u0, p = orc.batch_scenario(orc.PENDULUM, batch)
+    batch = min(batch, n_all or batch)
 
     def leg(n_inst, nthreads, budget):
         ctrls = []
@@ -75,7 +96,7 @@ def cpu_baseline(batch, tol, warm, seconds_budget):
         return n_inst * ticks / secs, ticks, float(ks.mean())
 
     v_all, t_all, k_all = leg(batch, threads, seconds_budget)
-    n1 = min(256, batch)
+    n1 = min(256 if warm <= 100 else 16, batch)
     v_one, t_one, _ = leg(n1, 1, seconds_budget)
     return {"value": v_all, "unit": "control steps/s", "cores": threads, "kind": "port",
             "sample": f"oracle/liboracle.so (CPU restatement, bit-exact vs reference), {batch} controllers x "
@@ -88,26 +109,36 @@ def cpu_baseline(batch, tol, warm, seconds_budget):
 
 def committed_traffic(kernel_variant, ticks_per_launch, batch):
     """HBM bytes per launch from the COMMITTED rocprofv3 PMC passes of this command at this per-GPU batch (not measured
-    in this run): profiles/r<NN>_wg_bench[_B<batch>]_pmc.json, newest round first."""
+    in this run): profiles/r<NN>_(wg|wave)_bench[_B<batch>]_pmc.json, newest round first.  Only a profile taken with the
+    very library this process times is quoted (`library_sha256_16` in the profile): returns (bytes, path, why_not)."""
     import glob
     import re
-    if kernel_variant not in (2, 3):
-        return None, None
+    if kernel_variant not in (2, 3, 4):
+        return None, None, "no committed counter profile for this mapping"
     cands = []
-    for path in glob.glob(os.path.join(ROOT, "profiles", "r*_wg_bench*_pmc.json")):
-        m = re.match(r"r(\d+)_wg_bench(?:_B(\d+))?_pmc\.json$", os.path.basename(path))
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r*_bench*_pmc.json")):
+        m = re.match(r"r(\d+)_(?:wg|wave)_bench(?:_B(\d+))?_pmc\.json$", os.path.basename(path))
         if m and int(m.group(2) or GLOBAL_BATCH) == batch:
             cands.append((int(m.group(1)), path))
+    mine = library_hash()
+    why = "no committed counter profile of this command at this batch"
     for _, path in sorted(cands, reverse=True):
         try:
             s = json.load(open(path))
         except (OSError, ValueError):
             continue
-        lean = "true, " in s.get("kernel", "").split("16, 10,")[-1][:8]  # <..., 16, 10, LEAN, PAR>
-        if "tick_wg_kernel" in s.get("kernel", "") and s.get("ticks_per_launch", 1) == ticks_per_launch \
-                and lean == (kernel_variant == 3):
-            return s["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
-    return None, None
+        kern = s.get("kernel", "")
+        if KERNEL_OF_VARIANT[kernel_variant] not in kern or s.get("ticks_per_launch", 1) != ticks_per_launch:
+            continue
+        if kernel_variant in (2, 3):
+            lean = "true, " in kern.split("16, 10,")[-1][:8]  # <..., 16, 10, LEAN, PAR>
+            if lean != (kernel_variant == 3):
+                continue
+        if s.get("library_sha256_16") != mine:
+            why = f"{os.path.relpath(path, ROOT)} was taken with another build of the library"
+            continue
+        return s["hbm_bytes_per_launch"], os.path.relpath(path, ROOT), None
+    return None, None, why
 
 
 from tests.parity_gate import OracleSample, ParityError, gate_continuation, sample_of  # noqa: E402  (the checker)
@@ -251,10 +282,13 @@ def main():
         us, _, _, _ = orc.closed_loop(c, x0, ticks)
         return bool((~np.isfinite(us)).any() or np.nanmax(np.abs(us)) > 1e6)
 
-    def measure(inputs, tol, steps, warmup, reps, check, flags=None, fatal=True):
+    def measure(inputs, tol, steps, warmup, reps, check, flags=None, fatal=True, also_fixed_k=False):
         """Closed loop of this rank's shard: warm-up, then `reps` timed regions of exactly `steps` ticks.
         A failed parity gate ends the script (the headline: no number without parity) or, for a SECONDARY leg
-        (fatal=False), comes back as {"error": ...} so that the leg is reported as failed without a number."""
+        (fatal=False), comes back as {"error": ...} so that the leg is reported as failed without a number.
+        also_fixed_k: a second controller batch with tol = 0 takes over the state the warm-up left (t, U, dUdt, x) and
+        is timed for `steps` ticks from there — the fixed-k figure for the SAME controller/plant state as the early-exit
+        leg that follows (its result is not fed back)."""
         x0_h, u0_h, p_h = inputs
         B = len(x0_h)
         ctrl = cg.CgmresBatch(MODEL, batch=B, dv=DV, k_max=KMAX, tol=tol, device=local, stream=stream,
@@ -280,6 +314,23 @@ def main():
                 parity["arnoldi_count_flips"] = chk.flips
         except ParityError as e:
             err = str(e)
+        fixed_k_ms = None
+        if also_fixed_k and err is None:
+            c0 = cg.CgmresBatch(MODEL, batch=B, dv=DV, k_max=KMAX, tol=0.0, device=local, stream=stream,
+                                variant=args.variant, flags=args.flags if flags is None else flags)
+            c0.set_ptau_repeat(p_h)
+            t_now, U_now, d_now = ctrl.get_state()
+            best = None
+            for _ in range(max(1, reps)):
+                c0.set_state(t_now, U_now, d_now)
+                x0c, u0c = x.clone(), u.clone()
+                torch.cuda.synchronize()
+                c0.timer_start()
+                c0.closed_loop_device(x0c, u0c, steps)
+                ms = c0.timer_stop()
+                best = ms if best is None else min(best, ms)
+            fixed_k_ms = {"ms_per_step": best / steps, "variant_name": c0.variant_name}
+            c0.close()
         walls, kernels, own = [], [], []
         for _ in range(reps):
             torch.cuda.synchronize()
@@ -347,7 +398,8 @@ def main():
         if world > 1:
             dist.all_gather(per_rank, mine)
         return {"B": B, "wall": med, "kernel_ms": kernels[walls.index(med)], "walls": walls, "n_ax": n_ax,
-                "parity": parity, "rank_kernel_ms": [t.item() for t in per_rank], "variant_name": resolved["variant_name"]}
+                "parity": parity, "rank_kernel_ms": [t.item() for t in per_rank], "variant_name": resolved["variant_name"],
+                "fixed_k_same_state": fixed_k_ms}
 
     n_check = args.check_sample if world == 1 else max(8, args.check_sample // world)
     inputs = shard_inputs(args.batch)
@@ -357,15 +409,17 @@ def main():
     value = args.batch * args.steps / m["wall"]
     ms_per_step = m["wall"] * 1e3 / args.steps
     # one launch of the wg mapping = TICKS_PER_LAUNCH consecutive ticks of the batch (the lane mapping: one tick)
-    tpl = cg.TICKS_PER_LAUNCH if head["variant"] in (2, 3) else 1  # (3 = wg-lean: same kernel, half the LDS)
+    tpl = cg.TICKS_PER_LAUNCH if head["variant"] in (2, 3, 4) else 1  # (3 = wg-lean: same kernel, half the LDS; 4 = wave)
     n_launches = -(-args.steps // tpl)
     launch_ms = m["kernel_ms"] / n_launches
     bytes_per_tick = float(sum(algorithmic_bytes(int(k)) for k in m["n_ax"])) if args.tol > 0 else \
         float(B * algorithmic_bytes(KMAX))
     bytes_per_launch = bytes_per_tick * args.steps / n_launches
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
-    traffic, traffic_src = committed_traffic(head["variant"], args.steps / n_launches, B) \
-        if args.tol == 0.0 else (None, None)
+    traffic, traffic_src, traffic_why = committed_traffic(head["variant"], args.steps / n_launches, B) \
+        if args.tol == 0.0 else (None, None, "early-exit mode: the profiles are fixed-k")
+    flops_per_tick = float(sum(algorithmic_flops(int(k)) for k in m["n_ax"])) if args.tol > 0 else \
+        float(B * algorithmic_flops(KMAX))
 
     def k_hist(n_ax):
         return [int(v) for v in np.bincount(np.asarray(n_ax, dtype=np.int64), minlength=KMAX + 1)[:KMAX + 1]]
@@ -379,6 +433,7 @@ def main():
         by = float(sum(algorithmic_bytes(int(k)) for k in m2["n_ax"])) * world  # (this rank's shard x ranks)
         return {"tol": 1e-6, "warmup_ticks": warm, "global_batch": n_global, "variant_name": m2["variant_name"],
                 "value": n_global * args.steps / m2["wall"], "ms_per_step": m2["wall"] * 1e3 / args.steps,
+                "fixed_k_from_the_same_state": m2.get("fixed_k_same_state"),
                 "mean_arnoldi_last_tick": float(np.mean(m2["n_ax"])), "k_histogram_last_tick_rank0": k_hist(m2["n_ax"]),
                 "algorithmic_frac_of_peak": by / (m2["wall"] / args.steps) / 1e9 / HBM_PEAK_GBS / world,
                 "parity": m2["parity"]}
@@ -398,11 +453,17 @@ def main():
     if not args.no_ref_mode and args.tol == 0.0:
         reps2 = max(1, min(args.reps, 3))
         ref_mode = early_exit_leg(soft(lambda: measure(inputs, 1e-6, args.steps, args.ref_warmup, reps2, n_check,
-                                                       fatal=False)), args.batch, args.ref_warmup)
+                                                       fatal=False, also_fixed_k=True)), args.batch, args.ref_warmup)
         ref_mode.setdefault("note", "")
-        ref_mode["note"] += ("every workgroup is resident (one per CU): a launch lasts as long as its slowest workgroup, "
-                            "so WHERE the instances sit cannot shorten it; placement by count is measured below on a "
-                            "batch that needs several rounds of workgroups")
+        ref_mode["note"] += ("wg mapping: every workgroup is resident (one per CU) and a launch lasts as long as its "
+                            "slowest workgroup, so WHERE the instances sit cannot shorten it (placement by count is "
+                            "measured below on a batch that needs several rounds of workgroups); wave mapping: every "
+                            "controller is its own wavefront and simply leaves its Arnoldi loop")
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            # the reference's own mode on the host cores, from the same warmed-up state (one instance per thread: the
+            # long warm-up is what bounds the sample)
+            ref_mode["cpu_baseline"] = soft(lambda: cpu_baseline(args.batch, 1e-6, args.ref_warmup, args.cpu_seconds,
+                                                                 n_all=len(os.sched_getaffinity(0))))
         if args.binning_batch and world == 1:
             big = shard_inputs(args.binning_batch)
             legs = {}
@@ -421,10 +482,22 @@ def main():
             {"scaling": "weak", "batch_per_gpu": mw["B"], "global_batch": args.batch * world,
              "value": args.batch * world * args.steps / mw["wall"], "ms_per_step": mw["wall"] * 1e3 / args.steps}
 
-    kernel_name = "tick_lane_kernel" if head["variant"] == 1 else f"tick_wg_kernel [{head['variant_name']}]"
+    kernel_name = "tick_lane_kernel" if head["variant"] == 1 else \
+        f"{KERNEL_OF_VARIANT[head['variant']]} [{head['variant_name']}]"
+    flops_per_launch = flops_per_tick * args.steps / n_launches
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source_committed_profile": traffic_src,
+                "traffic_unavailable_because": traffic_why,
                 "measured_GBps": (traffic / (launch_ms * 1e-3) / 1e9) if traffic else None,
+                # what the counters say HBM really moved, and the fp64 VALU view of the same launch: neither binds
+                "hbm_measured_frac": (traffic / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                "valu_frac": flops_per_launch / (launch_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                "algorithmic_fp64_flops_per_launch": flops_per_launch, "valu_peak_TFLOPs": FP64_VALU_PEAK_TFLOPS,
+                "bound_observed": "issue",
+                "bound_observed_note": "at this batch a tick is a chain of instruction issues (one instruction per ~4.4 "
+                                       "cycles and wave, DESIGN.md 4.1/4.5): `frac` is the metric's algorithmic-byte model / "
+                                       "time, `hbm_measured_frac` what the counters say HBM moved, `valu_frac` the fp64 view",
+                "library_sha256_16": library_hash(),
                 "kernel": f"{kernel_name} ({tpl} control step(s) of the batch per launch)", "launch_ms": launch_ms,
                 "ticks_per_launch": args.steps / n_launches, "algorithmic_bytes_per_launch": bytes_per_launch,
                 "rank": 0, "instances_per_launch": B}

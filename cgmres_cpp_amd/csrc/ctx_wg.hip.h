@@ -159,12 +159,13 @@ struct CtxWg final : cgmres_hip_ctx {
     } else if (cfg.variant == 0 && lean_ok && (cfg.batch + 15) / 16 > cus) {
       lean = true;
     }
-    // the latency mapping: asked for, or (library's choice) when the batch leaves most of the GPU's SIMDs without a
-    // controller of their own on the wg mapping
+    // the latency mapping: asked for, or (library's choice) up to two controllers per SIMD.  One wave per SIMD runs a
+    // tick in ~43 us (wg: ~117 us whatever the batch); the kernel takes all 512 registers, so a batch beyond one
+    // controller per SIMD runs in rounds: two rounds (~88 us) still beat the wg mapping, three do not.
     if (cfg.variant == 4) {
       if (!wave_supported(cfg)) return fail(CGMRES_HIP_EINVAL, "wave mapping: model / dtype / dv = %d / k_max = %d not supported", cfg.dv, cfg.k_max);
       wave = true;
-    } else if (cfg.variant == 0 && wave_supported(cfg) && cfg.batch <= 4 * cus && !(cfg.flags & CGMRES_HIP_FLAG_NO_WAVE)) {
+    } else if (cfg.variant == 0 && wave_supported(cfg) && cfg.batch <= 8 * cus && !(cfg.flags & CGMRES_HIP_FLAG_NO_WAVE)) {
       wave = true;
     }
     if (lean) plan = PLAN_LEAN, fh_hbm = 0, lds_bytes = lean_bytes;

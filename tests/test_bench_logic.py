@@ -101,11 +101,21 @@ def test_bench_gpus_2_from_a_plain_invocation_reaches_a_world_of_two():
     assert r.returncode != 0
 
 
-def test_bench_handles_every_wg_variant_in_its_bookkeeping():
+def test_bench_handles_every_fused_variant_in_its_bookkeeping(monkeypatch):
     b = _bench()
     src = open(os.path.join(ROOT, "bench.py")).read()
-    assert 'head["variant"] in (2, 3)' in src              # wg-lean fuses 10 ticks per launch like wg
-    # committed PMC traffic is looked up per per-GPU batch and per LDS plan
-    t, path = b.committed_traffic(2, 10, 4096)
-    assert t and path.startswith("profiles/")
-    assert b.committed_traffic(1, 1, 4096) == (None, None)
+    assert 'head["variant"] in (2, 3, 4)' in src           # wg-lean and wave fuse 10 ticks per launch like wg
+    # Committed PMC traffic is looked up per per-GPU batch, per mapping and per LDS plan, and is only quoted when the
+    # profile was taken with the very library being timed.
+    import json
+    prof = json.load(open(os.path.join(ROOT, "profiles", "r03_wg_bench_pmc.json")))
+    monkeypatch.setattr(b, "library_hash", lambda: prof.get("library_sha256_16"))
+    t, path, why = b.committed_traffic(2, 10, 4096)
+    assert t and path.startswith("profiles/") and why is None
+    monkeypatch.setattr(b, "library_hash", lambda: "0123456789abcdef")
+    t, path, why = b.committed_traffic(2, 10, 4096)
+    assert t is None and path is None and "another build" in why
+    assert b.committed_traffic(1, 1, 4096)[:2] == (None, None)
+    assert b.KERNEL_OF_VARIANT[4] == "tick_wave_kernel"
+    # the secondary (VALU) view: SURVEY.md 8(d)'s flop count of one pendulum instance-tick at k = 10
+    assert b.algorithmic_flops(10) == 13 * 50 * 111 + 13 * 600 + 4 * 150 * 55 + 4500 + 14 * 300

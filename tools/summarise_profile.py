@@ -23,6 +23,13 @@ out = {"command": ("python3 " + open(cmd_file).read().strip().replace(root + "/"
 stats = list(csv.DictReader(open(os.path.join(dst, f"{name}_kernel_stats.csv"))))
 k = max(stats, key=lambda r: float(r["TotalDurationNs"]))
 out["kernel"] = k["Name"]
+try:  # the library the profile was taken with (bench.py quotes counters only next to a timing of the same build)
+    import hashlib
+    sys.path.insert(0, root)
+    from cgmres_cpp_amd import build as _b
+    out["library_sha256_16"] = hashlib.sha256(open(os.environ.get("CGMRES_HIP_LIB") or _b.LIB_PATH, "rb").read()).hexdigest()[:16]
+except OSError:
+    out["library_sha256_16"] = None
 out["kernel_calls"] = int(k["Calls"])
 out["kernel_avg_ns"] = float(k["AverageNs"])
 for kind, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
