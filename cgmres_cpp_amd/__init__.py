@@ -32,7 +32,7 @@ SYMBOLS = [
     "cgmres_hip_device_count", "cgmres_hip_create", "cgmres_hip_destroy", "cgmres_hip_get_config", "cgmres_hip_variant_name",
     "cgmres_hip_set_ptau", "cgmres_hip_set_ptau_repeat", "cgmres_hip_init_u0", "cgmres_hip_init_u0_newton",
     "cgmres_hip_control", "cgmres_hip_control_device", "cgmres_hip_closed_loop_device",
-    "cgmres_hip_closed_loop_device_ptau", "cgmres_hip_synchronize",
+    "cgmres_hip_closed_loop_device_ptau", "cgmres_hip_synchronize", "cgmres_hip_shard_bounds",
     "cgmres_hip_get_time", "cgmres_hip_get_state", "cgmres_hip_set_state", "cgmres_hip_get_status",
     "cgmres_hip_get_krylov", "cgmres_hip_F_func", "cgmres_hip_prepare", "cgmres_hip_Ax_func", "cgmres_hip_gmres",
     "cgmres_hip_timer_start", "cgmres_hip_timer_stop", "cgmres_hip_malloc", "cgmres_hip_free",
@@ -94,6 +94,7 @@ def load():
     lib.cgmres_hip_closed_loop_device.argtypes = [vp, vp, vp, i32]
     lib.cgmres_hip_closed_loop_device_ptau.argtypes = [vp, vp, vp, i32, vp, C.c_int]
     lib.cgmres_hip_synchronize.argtypes = [vp]
+    lib.cgmres_hip_shard_bounds.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
     lib.cgmres_hip_get_time.argtypes = [vp, C.POINTER(C.c_double)]
     lib.cgmres_hip_get_state.argtypes = [vp, C.POINTER(C.c_double), vp, vp]
     lib.cgmres_hip_set_state.argtypes = [vp, C.c_double, vp, vp]

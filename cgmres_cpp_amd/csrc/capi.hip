@@ -397,6 +397,14 @@ int cgmres_hip_closed_loop_device_ptau(cgmres_hip_handle h, void* x, void* u, in
   if (h->np && !ptau_seq) return fail(CGMRES_HIP_EINVAL, "closed_loop_device_ptau: null ptau sequence");
   return h->closed_loop(x, u, n_ticks, h->np ? ptau_seq : nullptr, per_instance);
 }
+int cgmres_hip_shard_bounds(int32_t n, int32_t world, int32_t rank, int32_t* lo, int32_t* hi) {
+  if (n < 0 || world < 1 || rank < 0 || rank >= world || !lo || !hi)
+    return fail(CGMRES_HIP_EINVAL, "shard_bounds: n = %d, world = %d, rank = %d", n, world, rank);
+  const int32_t base = n / world, extra = n % world;
+  *lo = rank * base + (rank < extra ? rank : extra);
+  *hi = *lo + base + (rank < extra ? 1 : 0);
+  return 0;
+}
 int cgmres_hip_synchronize(cgmres_hip_handle h) {
   NEED(h);
   HIP_TRY(hipSetDevice(h->cfg.device));

@@ -202,6 +202,13 @@ int cgmres_hip_Ax_func(cgmres_hip_handle h, void* out, const void* v);
 /* Gmres::gmres(x, b), gmres.hpp:28-112; needs cgmres_hip_prepare first. x [batch][len] in/out. */
 int cgmres_hip_gmres(cgmres_hip_handle h, void* x, const void* b);
 
+/* ---- sharding a batch over the GPUs of one node ------------------------------------- */
+/* Contiguous, balanced slice [*lo, *hi) of `n` controller instances for shard `rank` of `world` (the first n % world
+ * shards get one more) — the rule cgmres_cpp_amd/sharding.py and include/cgmres_batch.hpp (CgmresBatchSharded) share.
+ * The reference's multiple_controller/main.cpp:89-110 owns its controllers one by one; this is the bookkeeping of
+ * owning `n` of them on `world` devices.  Pure host arithmetic: needs no GPU. */
+int cgmres_hip_shard_bounds(int32_t n, int32_t world, int32_t rank, int32_t* lo, int32_t* hi);
+
 /* ---- measurement ---------------------------------------------------------------------------------- */
 /* HIP events on the handle's stream around whatever is enqueued between the two calls. */
 int cgmres_hip_timer_start(cgmres_hip_handle h);

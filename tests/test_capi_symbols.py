@@ -65,6 +65,19 @@ def test_argument_validation_and_no_cpu_fallback(lib):
     assert lib.cgmres_hip_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
     cfg.dv = 20000  # dim_u*dv beyond the reference's int16 index range
     assert lib.cgmres_hip_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    cfg.dv = 25
+    cfg.reserved = 7  # documented as 0: refused, so the field can be given a meaning later
+    assert lib.cgmres_hip_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    assert b"reserved" in lib.cgmres_hip_last_error()
+    cfg.reserved = 0
+    cfg.flags = 1 << 20
+    assert lib.cgmres_hip_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    assert b"unknown flags" in lib.cgmres_hip_last_error()
+    cfg.flags = 0
+    cfg.variant = 5
+    assert lib.cgmres_hip_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+    assert b"unknown variant" in lib.cgmres_hip_last_error()
+    cfg.variant = 0
     if cg.device_count() == 0:
         with pytest.raises(cg.CgmresHipError, match="no HIP device|no CPU path"):
             cg.CgmresBatch("pendulum", batch=4)

@@ -104,6 +104,21 @@ def test_example_program_reproduces_reference_loop(tmp_path, which, fixture, nco
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,devices,ticks", [(300, "0,0", 25), (67, "0,0,0", 12), (4100, "0,0", 11)])
+def test_sharded_batch_in_cpp_equals_the_unsharded_batch(B, devices, ticks):
+    """include/cgmres_batch.hpp: CgmresBatchSharded<Model> — one handle + stream per listed device, host vectors cut by
+    cgmres_hip_shard_bounds, the closed loop resident on every shard, one gather at the end — against unsharded
+    CgmresBatch runs of the same instances, bit for bit (controllers are independent).  Both shards sit on the one
+    card of the test box; the uneven splits (150 + 150, 23 + 22 + 22, 2050 + 2050: wave and wg mappings) are on purpose."""
+    exe = os.path.join(BUILD, "closed_loop")
+    _make("all")
+    r = subprocess.run([exe, "sharded", str(B), devices, str(ticks)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "max |sharded - single| = 0;" in r.stdout, r.stdout
+    assert r.stdout.count("shard ") >= len(devices.split(","))
+
+
+@pytest.mark.gpu
 def test_unmodified_reference_main_runs_on_gpu(tmp_path):
     """The reference's own arm_type_inverted_pendulum/main.cpp, compiled unchanged against the façade in the build
     container (oracle/_ref/mains/), run here: its output file must start with the reference's numbers."""

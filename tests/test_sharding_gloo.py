@@ -24,6 +24,27 @@ def test_shard_bounds_cover_and_balance():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_c_abi_shard_bounds_is_the_same_rule():
+    """cgmres_hip_shard_bounds (what include/cgmres_batch.hpp's CgmresBatchSharded cuts its host vectors by) ==
+    cgmres_cpp_amd.sharding.shard_bounds (what bench.py's ranks use); pure host arithmetic, no GPU."""
+    import ctypes as C
+    import cgmres_cpp_amd as cg
+    from cgmres_cpp_amd.sharding import shard_bounds
+    L = cg.load()
+    L.cgmres_hip_shard_bounds.argtypes = [C.c_int32] * 3 + [C.POINTER(C.c_int32)] * 2
+    for n in (2, 7, 8, 4096, 4099, 8192):
+        for world in (1, 2, 3, 4, 8):
+            if n < world:
+                continue
+            for r in range(world):
+                lo, hi = C.c_int32(), C.c_int32()
+                assert L.cgmres_hip_shard_bounds(n, world, r, C.byref(lo), C.byref(hi)) == 0
+                assert (lo.value, hi.value) == shard_bounds(n, world, r)
+    lo, hi = C.c_int32(), C.c_int32()
+    assert L.cgmres_hip_shard_bounds(10, 2, 2, C.byref(lo), C.byref(hi)) == -1   # CGMRES_HIP_EINVAL
+    assert L.cgmres_hip_shard_bounds(10, 0, 0, C.byref(lo), C.byref(hi)) == -1
+
+
 WORKER = textwrap.dedent('''
     import os, sys, json
     sys.path.insert(0, os.environ["REPO_ROOT"])
