@@ -75,9 +75,13 @@ struct WgParams {
   T* park;                             // [workgroups*IPW][Lv]: the solution vector during the Arnoldi loop (MAXM > 10 only)
   int *n_ax, *reason;
   // Placement: slot q = workgroup*IPW + row of the launch holds instance perm[q] (null = identity).  Instances never
-  // exchange data, so any placement gives the same bits per instance; the closed loop of an oversubscribed batch bins
-  // instances by the Arnoldi count of their last tick so that the rows of a workgroup leave the loop together
-  // (gmres.hpp:93-95 makes the count data-dependent; util_kernels.hip.h: bin_by_count_kernel).
+  // exchange data; the closed loop of an oversubscribed batch bins instances by the Arnoldi count of their last tick so
+  // that the rows of a workgroup leave the loop together (gmres.hpp:93-95 makes the count data-dependent;
+  // util_kernels.hip.h: bin_by_count_kernel, a stable sort: the same counts give the same placement).  Where an
+  // instance sits changes its bits in ONE case: the pendulum's quad sweep picks the form of its trig update (rotation /
+  // fresh evaluation, sweep_state) per WAVE, i.e. for the 16 instances of a workgroup together, and the two forms round
+  // differently (~1e-16) — in fast motion an instance's rounding depends on its workgroup mates.  Everything else of a
+  // tick is independent of the placement bit for bit.
   const int* perm;
   const T* x_in;  // [B][NX]
   T* u_out;       // [B][NU]

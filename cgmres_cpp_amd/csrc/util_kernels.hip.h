@@ -111,33 +111,55 @@ __global__ void probe_kernel(const double* x, const double* u, const double* p, 
 
 // Placement of an oversubscribed batch (WgParams::perm): instances grouped by the Arnoldi count of their last tick,
 // the long-running ones FIRST (the hardware hands workgroups out in index order, so the expensive ones start early and
-// the cheap ones fill the tail).  A counting sort of the B keys by one workgroup; the order inside a group is whatever
-// the atomics give — placement never changes an instance's bits.  key: n_ax[b] in 0..kmax (gmres.hpp:93-95).
+// the cheap ones fill the tail).  A STABLE counting sort of the B keys by one workgroup: inside a count group the
+// instances keep their caller order (rank = number of earlier instances with the same key, from wave ballots and a
+// per-wave count table), so the same counts always give the same placement — runs are reproducible.
+// key: n_ax[b] in 0..kmax (gmres.hpp:93-95), clamped to 64 groups.
 template <int UNUSED = 0>  // (a template: this header is included by several translation units)
 __global__ __launch_bounds__(1024) void bin_by_count_kernel(int* __restrict__ perm, const int* __restrict__ n_ax, int B, int kmax) {
-  __shared__ int cnt[66];
-  const int nb = kmax + 1 < 64 ? kmax + 1 : 64;
-  for (int q = threadIdx.x; q < 66; q += blockDim.x) cnt[q] = 0;
+  constexpr int NB = 64, NW = 16;
+  __shared__ int start[NB];      // next free slot of every group
+  __shared__ int wcnt[NW][NB];   // per pass: members of group k in wave w
+  const int nb = kmax + 1 < NB ? kmax + 1 : NB;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  auto key_of = [&](int b) {
+    int k = b < B ? n_ax[b] : -1;
+    return k < 0 ? (b < B ? 0 : -1) : (k >= nb ? nb - 1 : k);
+  };
+  for (int q = tid; q < NB; q += blockDim.x) start[q] = 0;
   __syncthreads();
-  for (int b = threadIdx.x; b < B; b += blockDim.x) {
-    int k = n_ax[b];
-    k = k < 0 ? 0 : (k >= nb ? nb - 1 : k);
-    atomicAdd(&cnt[k], 1);
-  }
+  for (int b = tid; b < B; b += blockDim.x) atomicAdd(&start[key_of(b)], 1);  // (counts only: order-free)
   __syncthreads();
-  if (threadIdx.x == 0) {  // start offsets, largest count first
+  if (tid == 0) {  // start offsets, largest count first
     int off = 0;
     for (int k = nb - 1; k >= 0; --k) {
-      const int c = cnt[k];
-      cnt[k] = off;
+      const int c = start[k];
+      start[k] = off;
       off += c;
     }
   }
   __syncthreads();
-  for (int b = threadIdx.x; b < B; b += blockDim.x) {
-    int k = n_ax[b];
-    k = k < 0 ? 0 : (k >= nb ? nb - 1 : k);
-    perm[atomicAdd(&cnt[k], 1)] = b;
+  for (int base = 0; base < B; base += blockDim.x) {  // 1024 consecutive instances per pass, in caller order
+    const int b = base + tid, k = key_of(b);
+    int rank = 0;
+    for (int g = 0; g < nb; ++g) {
+      const unsigned long long m = __ballot(k == g);
+      if (k == g) rank = __popcll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) wcnt[wave][g] = __popcll(m);
+    }
+    __syncthreads();
+    if (k >= 0) {
+      int before = 0;
+      for (int w = 0; w < wave; ++w) before += wcnt[w][k];
+      perm[start[k] + before + rank] = b;
+    }
+    __syncthreads();
+    if (tid < nb) {
+      int tot = 0;
+      for (int w = 0; w < NW; ++w) tot += wcnt[w][tid];
+      start[tid] += tot;
+    }
+    __syncthreads();
   }
 }
 
