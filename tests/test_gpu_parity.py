@@ -711,7 +711,10 @@ def test_device_sincos_accuracy():
 
 def test_variant_resolution():
     a = cg.CgmresBatch("pendulum", batch=4, dv=50, k_max=10)
-    assert a.variant == 2
+    assert a.variant == 4          # up to two controllers per SIMD: the wave mapping (tests/test_gpu_wave.py)
+    w = cg.CgmresBatch("pendulum", batch=4096, dv=50, k_max=10)
+    assert w.variant == 2          # the headline batch: one 16-instance workgroup per CU
+    w.close()
     # more 16-instance workgroups than CUs: the default becomes the lean LDS plan (two workgroups per CU) ...
     big = cg.CgmresBatch("pendulum", batch=8192, dv=100, k_max=20, dtype="f32")
     assert big.variant == 3
