@@ -78,13 +78,18 @@ __device__ __forceinline__ float wave_gather(float v, int src_lane) {
   return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane * 4, __float_as_int(v)));
 }
 
-// Sum over all 64 lanes, the same bits in every lane (each step adds the two operands of a commutative pair): the row
-// butterfly of dpp.hip.h, then the four row sums through scalar registers.
+// Sum over all 64 lanes as a wave-uniform value: a reduction INTO lane 63 — row_shr:1,2,4,8 bring every row's sum to its
+// lane 15, row_bcast:15 / row_bcast:31 (unmasked: only lane 63 has to be right) carry the row sums across — and one
+// readlane pair.  18 + 2 instructions, and the result lives in scalar registers (a free operand of the lanes' FMAs).
 template <class T>
 __device__ __forceinline__ T wave_sum(T x) {
-  x = row16_sum(x);
-  const T r0 = wave_bcast(x, 0), r1 = wave_bcast(x, 16), r2 = wave_bcast(x, 32), r3 = wave_bcast(x, 48);
-  return (r0 + r1) + (r2 + r3);
+  x += dpp_zero_fill<0x111, 0xf>(x);
+  x += dpp_zero_fill<0x112, 0xf>(x);
+  x += dpp_zero_fill<0x114, 0xf>(x);
+  x += dpp_zero_fill<0x118, 0xf>(x);
+  x += dpp_zero_fill<DPP_ROW_BCAST15, 0xf>(x);
+  x += dpp_zero_fill<DPP_ROW_BCAST31, 0xf>(x);
+  return wave_bcast(x, 63);
 }
 
 // ---- scans ---------------------------------------------------------------------------------------------------------

@@ -4,7 +4,7 @@
 // tests/golden/user_gmres_<op>.txt: the stand-alone solver of the device library (cgmres_hip_gmres_user) is pinned to
 // the reference itself.
 //   g++ -O3 -std=c++17 -ffp-contract=off -I/root/reference/include -I<repo> oracle/gmres_ref.cpp -o oracle/_ref/gmres_ref
-//   oracle/_ref/gmres_ref spd|convdiff  ->  one line per instance: b k_max tol | x[0..len) in %.17g
+//   oracle/_ref/gmres_ref spd|convdiff|convdiff150|convdiff300  ->  one line per instance: b k_max tol | x[0..len) in %.17g
 // Scenario of instance i (deterministic, shared with the tests): p_j = 0.3 + 0.11 i + 0.05 j (SPD) or
 // (0.4 + 0.07 i, 0.35 - 0.02 i) (conv-diff); b_e = sin(0.3 e + 0.5 i) + 0.1 e; x0_e = 0.01 (e - i); k_max and tol per
 // case below (early exits included).
@@ -37,12 +37,12 @@ class Solver : public Gmres {
 };
 
 template <class Op>
-void run(bool spd) {
+void run(bool spd, int n_inst = 12, int k_short = 5) {
   constexpr int L = Op::len;
-  const int kmaxs[3] = {spd ? 12 : 20, 30, 5};
+  const int kmaxs[3] = {spd ? 12 : 20, 30, k_short};
   const double tols[3] = {1e-9, 1e-6, 0.0};
   for (int c = 0; c < 3; ++c)
-    for (int i = 0; i < 12; ++i) {
+    for (int i = 0; i < n_inst; ++i) {
       double p[2] = {spd ? 0.3 + 0.11 * i : 0.4 + 0.07 * i, spd ? 0.0 : 0.35 - 0.02 * i};
       if (spd) p[0] += 0.05 * 0;
       double x[L], b[L];
@@ -58,6 +58,10 @@ void run(bool spd) {
 int main(int argc, char** argv) {
   if (argc > 1 && !strcmp(argv[1], "spd"))
     run<SpdTridiagOp>(true);
+  else if (argc > 1 && !strcmp(argv[1], "convdiff150"))
+    run<ConvDiffOp150>(false, 4, 10);
+  else if (argc > 1 && !strcmp(argv[1], "convdiff300"))
+    run<ConvDiffOp300>(false, 4, 10);
   else
     run<ConvDiffOp>(false);
   return 0;

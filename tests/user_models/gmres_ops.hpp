@@ -29,3 +29,21 @@ struct ConvDiffOp {  // nonsymmetric: convection-diffusion stencil with a varyin
     }
   }
 };
+
+// The same stencil at the vector lengths of the controller's own solves (dim_u * dv = 150 for the pendulum at N = 50, 300
+// for the two-mass system): what the one-wave-per-system solver is sized for.
+template <int N>
+struct ConvDiffOpN {
+  static constexpr int len = N, n_params = 2;
+  static void Ax(double* Ax, const double* x, const double* p) {
+    for (int i = 0; i < len; ++i) {
+      double a = (2.0 + p[0] + 0.01 * i) * x[i];
+      if (i > 0) a = a - (1.0 + p[1]) * x[i - 1];
+      if (i + 1 < len) a = a - (1.0 - p[1]) * x[i + 1];
+      a = a + 0.05 * x[(i * 7 + 3) % len];
+      Ax[i] = a;
+    }
+  }
+};
+using ConvDiffOp150 = ConvDiffOpN<150>;
+using ConvDiffOp300 = ConvDiffOpN<300>;

@@ -2,7 +2,7 @@
 """Secondary measurements (not bench lines): the other BASELINE.json configurations, closed loop on the device with
 the example plants, fixed-k mode (tol = 0) and reference mode (tol = 1e-6).
 
-    python tools/bench_configs.py [--config all|1|2|3|4|5|headline] [--steps K] [--warmup W] > gpurun_out/configs.jsonl
+    python tools/bench_configs.py [--config all|1|2|3|4|5|headline|gmres] [--steps K] [--warmup W] > gpurun_out/configs.jsonl
     python tools/bench_configs.py --gpus N --config 4        (N > 1: starts its own torch.distributed.run child, like bench.py)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/bench_configs.py --gpus N --config 4
 
@@ -173,7 +173,47 @@ def main():
         "2": ("cfg2 pendulum B=256", [(0, 256, 50, 10)], "f64"),
         "1": ("cfg1 one MSD controller N=20 k=5", [(1, 1, 20, 5)], "f64"),
     }
+    def run_gmres(batch=4096):
+        """Stand-alone Gmres with a caller-supplied operator (reference include/gmres.hpp:8-129) on the device: `batch`
+        independent systems through cgmres_hip_gmres_user, host pointers in and out (PCIe and the launch included),
+        checked against numpy's dense solve of the same systems."""
+        import cgmres_cpp_amd as cg
+        from cgmres_cpp_amd import plugin
+        ops = os.path.join(ROOT, "tests", "user_models", "gmres_ops.hpp")
+        for cls, name, L in (("ConvDiffOp150", "convdiff150", 150), ("ConvDiffOp300", "convdiff300", 300)):
+            oid = plugin.register_operator(plugin.build_operator(ops, cls, name=name))
+            e = np.arange(L)
+            i = np.arange(batch)[:, None]
+            P = np.concatenate([0.4 + 0.07 * (i % 12), 0.35 - 0.02 * (i % 12)], axis=1)
+            Bv = np.sin(0.3 * e[None, :] + 0.5 * i) + 0.1 * e[None, :]
+            X0 = 0.01 * (e[None, :] - (i % 12))
+            for kmax, tol in ((10, 0.0), (30, 1e-6)):
+                cg.gmres_user(oid, X0, Bv, kmax, tol, P)  # (first call: plugin workspace, code upload)
+                t0 = time.perf_counter()
+                x, n_ax, why = cg.gmres_user(oid, X0, Bv, kmax, tol, P)
+                dt = time.perf_counter() - t0
+                # residual of a sample against the dense operator
+                worst = 0.0
+                for b in (0, batch // 2, batch - 1):
+                    A = np.zeros((L, L))
+                    for r in range(L):
+                        A[r, r] += 2.0 + P[b, 0] + 0.01 * r
+                        if r > 0:
+                            A[r, r - 1] -= 1.0 + P[b, 1]
+                        if r + 1 < L:
+                            A[r, r + 1] -= 1.0 - P[b, 1]
+                        A[r, (r * 7 + 3) % L] += 0.05
+                    worst = max(worst, float(np.linalg.norm(A @ x[b] - Bv[b]) / np.linalg.norm(Bv[b])))
+                if rank == 0:
+                    print(json.dumps({"config": f"stand-alone Gmres, {cls} (len {L}), k_max {kmax}, tol {tol:g}", "batch": batch,
+                                      "ms_per_call_host_pointers": dt * 1e3, "systems_per_s": batch / dt,
+                                      "mean_arnoldi": float(np.mean(n_ax)), "worst_relative_residual_of_3": worst,
+                                      "kernel": "gmres_wave_kernel (one wavefront per system)"}), flush=True)
+
     keys = list(table) if args.config == "all" else args.config.split(",")
+    if "gmres" in keys:
+        run_gmres()
+        keys = [k for k in keys if k != "gmres"]
     for k in keys:
         label, members, dtype = table[k]
         for tol in [float(t) for t in args.tols.split(",")]:
