@@ -34,6 +34,17 @@ struct CtxWg final : cgmres_hip_ctx {
   T *stage = nullptr, *stage2 = nullptr;
   size_t stage_n = 0, stage2_n = 0;
   T *x_dev = nullptr, *u_dev = nullptr;
+  // control() through host pointers on a small batch (a single Cgmres<Model> object: batch 1): x and u travel through
+  // host-mapped pinned buffers the kernel reads / writes directly — one launch + one stream synchronisation per tick
+  // instead of copy, launch, copy, synchronise (each hipMemcpyAsync costs ~8 us of host time)
+  T *pin_x = nullptr, *pin_u = nullptr, *pin_x_dev = nullptr, *pin_u_dev = nullptr;
+  static constexpr int kPinnedIoMaxBatch = 1024;
+  ~CtxWg() override {
+    (void)hipSetDevice(cfg.device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    if (pin_x) (void)hipHostFree(pin_x);
+    if (pin_u) (void)hipHostFree(pin_u);
+  }
   int fh_hbm_for_hooks = 0;
   int* perm_dev = nullptr;   // placement of the next fused launch (bin_by_count_kernel)
   bool binning = false;      // closed loop: bin the instances by their last Arnoldi count before every launch
@@ -318,6 +329,20 @@ struct CtxWg final : cgmres_hip_ctx {
   int control_host(void* u, const void* x) override {
     HIP_TRY(hipSetDevice(cfg.device));
     if (!u || !x) return fail(CGMRES_HIP_EINVAL, "control: null pointer");
+    if (cfg.batch <= kPinnedIoMaxBatch) {
+      const size_t bx = size_t(cfg.batch) * nx * sizeof(T), bu = size_t(cfg.batch) * nu * sizeof(T);
+      if (!pin_x) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&pin_x), bx, hipHostMallocMapped));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&pin_u), bu, hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&pin_x_dev), pin_x, 0));
+        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&pin_u_dev), pin_u, 0));
+      }
+      std::memcpy(pin_x, x, bx);
+      if (int rc = launch_tick(pin_u_dev, pin_x_dev, nullptr)) return rc;
+      HIP_TRY(hipStreamSynchronize(stream));
+      std::memcpy(u, pin_u, bu);
+      return 0;
+    }
     HIP_TRY(hipMemcpyAsync(x_dev, x, size_t(cfg.batch) * nx * sizeof(T), hipMemcpyHostToDevice, stream));
     if (int rc = launch_tick(u_dev, x_dev, nullptr)) return rc;
     HIP_TRY(hipMemcpyAsync(u, u_dev, size_t(cfg.batch) * nu * sizeof(T), hipMemcpyDeviceToHost, stream));

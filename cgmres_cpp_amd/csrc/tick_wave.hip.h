@@ -38,13 +38,29 @@
 
 namespace cgm {
 
-// which models have the scans above
+// what a model's scans need to know about the lane
+struct WaveLane {
+  int lane, dv, msrc;  // msrc: the mirrored lane of the costate scans (stage dv-1-m on lane m; an involution on [0, dv))
+  bool in_hor;         // the lane has a stage with controls
+};
+
+// which models have the scans above, and how.  NONLINEAR: the state equation is not affine in x — Newton on the trajectory
+// from a base trajectory, serial sweeps in front of the solve (the code in the kernel); otherwise the model supplies
+//   state_scan  (L, u, xinit, dtau, x)            x(s) of every lane's stage from the lane's controls: ONE scan, exact
+//   costate_scan(L, x, u, p, dtau, phi, dF)       costate recurrence + dH/du pieces from the lane's stage
 template <class M>
-struct WaveOps : std::false_type {};
+struct WaveOps : std::false_type {  // (no wave scans: user models and whatever is not specialised below)
+  static constexpr bool NONLINEAR = false;
+  static constexpr int LDS_EXTRA = 0;
+};
 
 template <class T>
 struct WaveOps<PendulumDev<T>> : std::true_type {
   using M = PendulumDev<T>;
+  static constexpr bool NONLINEAR = true;
+  using TickConsts = GeoPowers<T>;  // powers of 1 - dtau As (x2 and l2 are geometric recurrences)
+  static constexpr int LDS_EXTRA = 0;
+  static __device__ __forceinline__ void make_consts(TickConsts& G, T dtau, const WaveLane&, T*) { G.make(T(1) - dtau * M::As); }
   // sin/cos of (base angle + dl) from the base pair, |dl| <= sqrt(rot_zmax) (Taylor polynomials of the wg mapping's
   // rotation stage, MathCtx::rot_sin / rot_cos)
   template <class MC>
@@ -63,6 +79,126 @@ struct WaveOps<PendulumDev<T>> : std::true_type {
   }
 };
 
+// semiactive_damper/model.hpp:36-55: x0' = x1, x1' = a x0 + b u0 x1 — affine in x for given controls: the state sweep IS
+// one scan of 2 x 2 affine maps (exact up to rounding, no iteration, no serial sweep anywhere), and so is the costate
+// recurrence (SemiactiveDev::costate_step).
+template <class T>
+struct WaveOps<SemiactiveDev<T>> : std::true_type {
+  using M = SemiactiveDev<T>;
+  static constexpr bool NONLINEAR = false;
+  struct TickConsts {};
+  static constexpr int LDS_EXTRA = 0;
+  static __device__ __forceinline__ void make_consts(TickConsts&, T, const WaveLane&, T*) {}
+  static __device__ __forceinline__ void state_scan(const WaveLane& L, const T* u, const T* xinit, T dtau, const TickConsts&,
+                                                    T* x) {
+    // y' = y + D y,  D = [[0, dtau], [dtau a, dtau b u0]]; lane 0 applies its map to the initial state
+    T D[4] = {T(0), dtau, dtau * M::a, dtau * M::b * u[0]};
+    const bool first = L.lane == 0;
+    const T y0 = first ? xinit[0] : T(0), y1 = first ? xinit[1] : T(0);
+    T c[2] = {y0 + D[1] * y1, y1 + fma_t(D[2], y0, D[3] * y1)};
+    scan_aff2(D, c);
+    x[0] = wave_shift_up(c[0], xinit[0]);
+    x[1] = wave_shift_up(c[1], xinit[1]);
+  }
+  static __device__ __forceinline__ void costate_scan(const WaveLane& L, const T* x, const T* u, const T*, T dtau,
+                                                      const TickConsts&, T* phi, T* dF) {
+    T bw[M::NBW], trig[1] = {T(0)};
+    M::stage_coeffs(bw, phi, x, u, nullptr, trig, dtau);
+    T xT[M::NX], lT[M::NX];
+#pragma unroll
+    for (int c = 0; c < M::NX; ++c) xT[c] = wave_bcast(x[c], L.dv);
+    M::dPhidx(lT, xT, nullptr);
+    T mb[M::NBW];
+#pragma unroll
+    for (int c = 0; c < M::NBW; ++c) mb[c] = wave_gather(bw[c], L.msrc);
+    const bool first = L.lane == 0;
+    const T i0 = first ? lT[0] : T(0), i1 = first ? lT[1] : T(0);
+    // n0 = l0 + bw2 + dtau a l1,  n1 = l1 + bw3 + dtau l0 + bw0 l1
+    T D[4] = {T(0), dtau * M::a, dtau, mb[0]};
+    T c[2] = {mb[2] + i0 + D[1] * i1, mb[3] + i1 + fma_t(D[2], i0, D[3] * i1)};
+    scan_aff2(D, c);
+    const T in1 = wave_shift_up(c[1], lT[1]);  // costate ENTERING the lane's stage
+    dF[0] = wave_gather(mb[1] * in1, L.msrc);  // B^T l of the stage (model.hpp:52)
+  }
+};
+
+// mass_spring_damper/model.hpp:36-64: linear and time-invariant — x' = x + dtau (A x + B u), l' = l + bw + dtau (Al l) with
+// CONSTANT 4 x 4 matrices (A from dxdt :36-41, Al from dHdx :50-55 — not each other's transpose: the reference's
+// k1*k2 / k1+k2 quirk).  Every composed matrix of a scan is a power of I + dtau A (resp. Al): one table of powers per
+// horizon step and recurrence in LDS (power_table4, built once per tick), then a sweep is two VECTOR-only scans.
+template <class T>
+struct WaveOps<MsdDev<T>> : std::true_type {
+  using M = MsdDev<T>;
+  static constexpr bool NONLINEAR = false;
+  static constexpr int TABLE = 32 * 16;              // scalars of one power table
+  static constexpr int LDS_EXTRA = 4 * TABLE;        // state + costate tables for dtau_h and for dtau_0
+  struct TickConsts {
+    const T *st, *co;
+  };
+  static __device__ __forceinline__ void make_consts(TickConsts& G, T dtau, const WaveLane& L, T* lds) {
+    const T A[16] = {T(0), T(0), T(1), T(0),                                                           // model.hpp:37
+                     T(0), T(0), T(0), T(1),                                                           // :38
+                     -(M::k1 * M::k2) / M::m1, M::k2 / M::m1, -(M::d1 + M::d2) / M::m1, M::d2 / M::m1,  // :39
+                     M::k2 / M::m2, -M::k2 / M::m2, M::d2 / M::m2, -M::d2 / M::m2};                    // :40
+    const T Al[16] = {T(0), T(0), -(M::k1 + M::k2) / M::m1, M::k2 / M::m2,    // :51
+                      T(0), T(0), M::k2 / M::m1, -M::k2 / M::m2,              // :52
+                      T(1), T(0), -(M::d1 + M::d2) / M::m1, M::d2 / M::m2,    // :53
+                      T(0), T(1), M::d2 / M::m1, -M::d2 / M::m2};             // :54
+    T D[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) D[e] = dtau * A[e];
+    power_table4(lds, D, L.lane);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) D[e] = dtau * Al[e];
+    power_table4(lds + TABLE, D, L.lane);
+    G.st = lds, G.co = lds + TABLE;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+  static __device__ __forceinline__ void state_scan(const WaveLane& L, const T* u, const T* xinit, T dtau, const TickConsts& G,
+                                                    T* x) {
+    const bool first = L.lane == 0;
+    T y[4], c[4] = {T(0), T(0), L.in_hor ? dtau * (u[0] / M::m1) : T(0), L.in_hor ? dtau * (u[1] / M::m2) : T(0)};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[r] = first ? xinit[r] : T(0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {  // lane 0 applies its map to the initial state: c += (I + D) x(0)
+      T a = c[r] + y[r];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a = fma_t(G.st[4 * r + k], y[k], a);
+      c[r] = a;
+    }
+    scan_const4(c, G.st, L.lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] = wave_shift_up(c[r], xinit[r]);
+  }
+  static __device__ __forceinline__ void costate_scan(const WaveLane& L, const T* x, const T* u, const T* p, T dtau,
+                                                      const TickConsts& G, T* phi, T* dF) {
+    T bw[M::NBW], trig[1] = {T(0)};
+    M::stage_coeffs(bw, phi, x, u, p, trig, dtau);
+    T xT[M::NX], pT[M::NP], lT[M::NX];
+#pragma unroll
+    for (int c = 0; c < M::NX; ++c) xT[c] = wave_bcast(x[c], L.dv);
+#pragma unroll
+    for (int j = 0; j < M::NP; ++j) pT[j] = wave_bcast(p[j], L.dv);
+    M::dPhidx(lT, xT, pT);
+    const bool first = L.lane == 0;
+    T c[4], y[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[r] = wave_gather(bw[r], L.msrc), y[r] = first ? lT[r] : T(0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      T a = c[r] + y[r];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a = fma_t(G.co[4 * r + k], y[k], a);
+      c[r] = a;
+    }
+    scan_const4(c, G.co, L.lane);
+    const T in2 = wave_shift_up(c[2], lT[2]), in3 = wave_shift_up(c[3], lT[3]);  // costate ENTERING the lane's stage
+    dF[0] = wave_gather(in2 / M::m1, L.msrc);  // model.hpp:58-59
+    dF[1] = wave_gather(in3 / M::m2, L.msrc);
+  }
+};
+
 // LDS of one wave: the table of the serial sweeps and two control rows for them (nothing else lives in memory)
 template <class M, class T>
 struct WaveLds {
@@ -75,8 +211,10 @@ struct WaveLds {
     const int t = 2 * tab_len(dv), v = (kmax + 1) * M::NU * dv;
     return ((t > v ? t : v) + 1) & ~1;
   }
+  // (models that are affine in x have no serial sweep and keep the basis in registers: only their own tables are in LDS)
   static __host__ __device__ size_t count_T(int dv, int kmax) {
-    return size_t(region_a(dv, kmax)) + tab_len(dv) + 2 * row_len(dv) + 2;
+    const size_t sweeps = WaveOps<M>::NONLINEAR ? size_t(region_a(dv, kmax)) + tab_len(dv) + 2 * row_len(dv) + 2 : 0;
+    return sweeps + WaveOps<M>::LDS_EXTRA + 2;
   }
   static __host__ __device__ size_t bytes(int dv, int kmax, int waves) {
     return ((count_T(dv, kmax) * sizeof(T) + 15) & ~size_t(15)) * waves;
@@ -119,8 +257,8 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(VLDS ?
   static_assert(std::is_same<T, double>::value, "the Newton thresholds are set for fp64");
   using W = WaveOps<M>;
   using Lds = WaveLds<M, T>;
-  constexpr int NX = M::NX, NU = M::NU, NP = M::NP;
-  static_assert(NX == 4 && NU == 3 && NP == 2, "pendulum shapes");
+  constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC, NUL = M::NUL;
+  constexpr bool NONLIN = W::NONLINEAR;
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
@@ -134,6 +272,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(VLDS ?
   T* const wrow = tab2 + Lds::tab_len(dv);              // [2][row_len]
   auto tab_of = [&](int q) { return q == 2 ? tab2 : base + q * Lds::tab_len(dv); };
   const int rlen = Lds::row_len(dv);
+  T* const lds_extra = W::NONLINEAR ? wrow + 2 * rlen + 2 : base;  // the model's own tables (WaveOps::LDS_EXTRA scalars)
   struct alignas(2 * sizeof(T)) WPair {
     T a, b;
   };
@@ -145,17 +284,22 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(VLDS ?
   const bool in_hor = lane < dv;    // the lane has a stage with controls
   const bool in_traj = lane <= dv;  // ... or the terminal stage
   const int msrc = in_hor ? dv - 1 - lane : lane;  // mirrored lane of the costate scans (an involution on [0, dv))
+  const WaveLane WL{lane, dv, msrc, in_hor};
 
   // ---- controller state of this instance
-  T U[NU], du[NU], Fh[NU], p[NP], xs[NX];
+  T U[NU], du[NU], Fh[NU], p[NP > 0 ? NP : 1], xs[NX];
   {
     const T* Ug = P.U + size_t(b) * P.Lg + lane * NU;
     const T* dg = P.dUdt + size_t(b) * P.Lg + lane * NU;
 #pragma unroll
     for (int j = 0; j < NU; ++j) U[j] = in_hor ? Ug[j] : T(0), du[j] = in_hor ? dg[j] : T(0);
-    const T* pg = P.ptau + size_t(b) * NP * (dv + 1) + lane * NP;
+    if constexpr (NP > 0) {
+      const T* pg = P.ptau + size_t(b) * NP * (dv + 1) + lane * NP;
 #pragma unroll
-    for (int j = 0; j < NP; ++j) p[j] = in_traj ? pg[j] : T(0);
+      for (int j = 0; j < NP; ++j) p[j] = in_traj ? pg[j] : T(0);
+    } else {
+      p[0] = T(0);
+    }
 #pragma unroll
     for (int c = 0; c < NX; ++c) xs[c] = P.x_in[size_t(b) * NX + c];
   }
@@ -164,7 +308,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(VLDS ?
 
   // ---- phase 3 of a sweep on the lanes: costate recurrence + the costate part of dH/du (cgmres.hpp:145-161) from the
   //      stage's state / trig / controls.  Returns phi (costate-free part of dH/du) and dF (to be added to component 0).
-  auto backward = [&](const T* x, const T* trig, const T* u, T dtau, const GeoPowers<T>& G, T* phi, T* dF) {
+  using TickConsts = typename W::TickConsts;
+  auto backward = [&](const T* x, const T* trig, const T* u, T dtau, const TickConsts& G, T* phi, T* dF) {
+   if constexpr (!NONLIN) {
+    W::costate_scan(WL, x, u, p, dtau, G, phi, dF);
+   } else {
     T bw[M::NBW];
     M::stage_coeffs(bw, phi, x, u, p, trig, dtau);
     // terminal costate from the terminal stage (lane dv), wave-uniform
@@ -191,17 +339,18 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(VLDS ?
     const T l2 = scan_geo(fma_t(mb[2], in3, fma_t(dtau, in0, G.pw[0] * i2)), G);
     const T in2 = wave_shift_up(l2, lT[2]);
     const T dFm = fma_t(mb[3], in3, in2 * M::Bs);  // B^T l of the stage (model.hpp:59)
-    *dF = wave_gather(dFm, msrc);
+    dF[0] = wave_gather(dFm, msrc);
+   }
   };
   // post-processing of a sweep result (cgmres.hpp:94-96, :173-174)
-  auto finish = [&](int mode, const T* phi, T dF, T* out) {
+  auto finish = [&](int mode, const T* phi, const T* dF, T* out) {
     const T sc_phi = mode == F_RHS ? P.one_m_zh : T(1.0);
     const T sc = mode == F_PLAIN ? T(1.0) : (mode == F_RHS ? P.one_m_zh * P.inv_h : P.inv_h);
 #pragma unroll
     for (int j = 0; j < NU; ++j) {
       T rj = phi[j];
       if (mode != F_PLAIN) rj = (rj * sc_phi - Fh[j]) * P.inv_h;
-      if (j == 0) rj = fma_t(dF, sc, rj);
+      if (j < NUL) rj = fma_t(dF[j < NUL ? j : 0], sc, rj);
       out[j] = in_hor ? rj : T(0);
     }
   };
@@ -215,6 +364,7 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(VLDS ?
   constexpr int ROT_HOLD = 64;
   int rot_hold = 0;
   auto serial_sweeps = [&](int q_lo, int q_hi, T dtau_h, T dtau_0) {
+   if constexpr (NONLIN) {
     auto run = [&](auto mode_tag) -> int {  // 0 = done, 1 = an increment left the rotation range, 2 = argument beyond the fast trig range
       constexpr int MODE = decltype(mode_tag)::value;
       const int q = lane >> 2, rho = lane & 3;
@@ -273,45 +423,70 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(VLDS ?
     if (__builtin_expect(st == 2, 0)) run(std::integral_constant<int, 2>{});
     if (rot_hold > 0) --rot_hold;
     wave_fence();
+   }
   };
   // the lane's stage of sweep q from the table: x[4] and {sin d, cos d, sin x1, cos x1}
   // x0(s), x2(s) of every lane's stage from the stage's control u0:  x2' = (1 - dtau As) x2 + dtau Bs u0,
   // x0' = x0 + dtau x2  (model.hpp:38,40) — a geometric scan and a prefix sum
-  auto lin_states = [&](T u0, const T* xinit, T dtau, const GeoPowers<T>& G, T* x0, T* x2) {
+  auto lin_states = [&](T u0, const T* xinit, T dtau, const TickConsts& G, T* x0, T* x2) {
+   if constexpr (NONLIN) {
     const bool first = lane == 0;
     const T e2 = (in_hor ? (dtau * M::Bs) * u0 : T(0)) + (first ? G.pw[0] * xinit[2] : T(0));
     *x2 = wave_shift_up(scan_geo(e2, G), xinit[2]);
     *x0 = wave_shift_up(scan_sum(dtau * *x2 + (first ? xinit[0] : T(0))), xinit[0]);
+   }
   };
   auto read_tab = [&](int q, T* x, T* tr4) {  // (x[0], x[2] are the caller's: lin_states)
+   if constexpr (NONLIN) {
     const WPair* pt = reinterpret_cast<const WPair*>(tab_of(q) + (in_traj ? lane : dv) * Lds::TAB_W);
     const WPair e0 = pt[0], e1 = pt[1], e2 = pt[2], e3 = pt[3];
     x[1] = e2.a, x[3] = e3.a;
     tr4[0] = e0.b, tr4[1] = e1.b, tr4[2] = e2.b, tr4[3] = e3.b;
+   }
   };
 
   const int nt = P.n_ticks;
   for (int tk = 0; tk < nt; ++tk) {
     const bool last = tk + 1 == nt;
     const T dtau_h = P.dtau_tab[2 * tk], dtau_0 = P.dtau_tab[2 * tk + 1];
-    if (P.ptau_seq) {  // set_ptau before this tick (cgmres.hpp:36-39)
-      const T* src = P.ptau_seq + size_t(tk) * P.pseq_tick + size_t(b) * P.pseq_inst + lane * NP;
+    if constexpr (NP > 0) {
+      if (P.ptau_seq) {  // set_ptau before this tick (cgmres.hpp:36-39)
+        const T* src = P.ptau_seq + size_t(tk) * P.pseq_tick + size_t(b) * P.pseq_inst + lane * NP;
 #pragma unroll
-      for (int j = 0; j < NP; ++j) p[j] = in_traj ? src[j] : T(0);
+        for (int j = 0; j < NP; ++j) p[j] = in_traj ? src[j] : T(0);
+      }
     }
     CGM_STAMP(0, 11);
-    GeoPowers<T> Gh, G0;  // powers of 1 - dtau As for the geometric scans of this tick
-    Gh.make(T(1) - dtau_h * M::As);
-    G0.make(T(1) - dtau_0 * M::As);
+    TickConsts Gh, G0;  // per-tick constants of the model's scans for the two horizon steps (pendulum: powers of 1 - dtau As)
+    W::make_consts(Gh, dtau_h, WL, lds_extra);
+    W::make_consts(G0, dtau_0, WL, lds_extra + W::LDS_EXTRA / 2);
     // ---- cgmres.hpp:83-85: x_dxh = x + h f(x, U_0)
     {
-      T u0[NU], f[NX], tr[M::NC];
+      T u0[NU], f[NX], tr[NC > 0 ? NC : 1];
 #pragma unroll
       for (int j = 0; j < NU; ++j) u0[j] = wave_bcast(U[j], 0);
       M::dxdt(f, xs, u0, tr, mc);
 #pragma unroll
       for (int c = 0; c < NX; ++c) xh[c] = f[c] * P.h + xs[c];
     }
+    T xb[NX], tb[4];  // NONLINEAR: base trajectory of this tick (sweep #1) on the lanes
+    T bb[NU], ax0[NU];
+    if constexpr (!NONLIN) {
+      // ---- the three sweeps in front of the solve, each ONE state scan + one costate scan (no serial sweep, no LDS)
+      T x[NX], phi[NU], dF[NUL], uu[NU], trig[1] = {T(0)};
+      W::state_scan(WL, U, xh, dtau_h, Gh, x);
+      backward(x, trig, U, dtau_h, Gh, phi, dF);
+      finish(F_PLAIN, phi, dF, Fh);  // cgmres.hpp:88
+      W::state_scan(WL, U, xs, dtau_0, G0, x);
+      backward(x, trig, U, dtau_0, G0, phi, dF);
+      finish(F_RHS, phi, dF, bb);  // :91-96
+#pragma unroll
+      for (int j = 0; j < NU; ++j) uu[j] = du[j] * P.h + U[j];  // :168-169
+      W::state_scan(WL, uu, xh, dtau_h, Gh, x);
+      backward(x, trig, uu, dtau_h, Gh, phi, dF);
+      finish(F_AX, phi, dF, ax0);  // :99 -> gmres.hpp:33
+      (void)xb, (void)tb;
+    } else {
     // ---- the three sweeps in front of the solve: #1 Fh = F(U, x+hf, t+h) (:88), #2 b (:91-96), #3 A*dUdt (:99 ->
     //      gmres.hpp:33), state sweeps side by side on three quads
     if (in_hor) {
@@ -326,21 +501,19 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(VLDS ?
     CGM_STAMP(0, 0);
     serial_sweeps(0, 3, dtau_h, dtau_0);
     CGM_STAMP(0, 1);
-    T xb[NX], tb[4];  // base trajectory of this tick (sweep #1) on the lanes
-    T bb[NU], ax0[NU];
     {
       read_tab(0, xb, tb);
       lin_states(U[0], xh, dtau_h, Gh, &xb[0], &xb[2]);
-      T phi[NU], dF, trig[3] = {tb[0], tb[1], tb[3]};
-      backward(xb, trig, U, dtau_h, Gh, phi, &dF);
+      T phi[NU], dF[NUL], trig[3] = {tb[0], tb[1], tb[3]};
+      backward(xb, trig, U, dtau_h, Gh, phi, dF);
       finish(F_PLAIN, phi, dF, Fh);
     }
     {
       T x[NX], t4[4];
       read_tab(1, x, t4);
       lin_states(U[0], xs, dtau_0, G0, &x[0], &x[2]);
-      T phi[NU], dF, trig[3] = {t4[0], t4[1], t4[3]};
-      backward(x, trig, U, dtau_0, G0, phi, &dF);
+      T phi[NU], dF[NUL], trig[3] = {t4[0], t4[1], t4[3]};
+      backward(x, trig, U, dtau_0, G0, phi, dF);
       finish(F_RHS, phi, dF, bb);
     }
     {
@@ -349,10 +522,11 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(VLDS ?
 #pragma unroll
       for (int j = 0; j < NU; ++j) uu[j] = du[j] * P.h + U[j];
       lin_states(uu[0], xh, dtau_h, Gh, &x[0], &x[2]);
-      T phi[NU], dF, trig[3] = {t4[0], t4[1], t4[3]};
-      backward(x, trig, uu, dtau_h, Gh, phi, &dF);
+      T phi[NU], dF[NUL], trig[3] = {t4[0], t4[1], t4[3]};
+      backward(x, trig, uu, dtau_h, Gh, phi, dF);
       finish(F_AX, phi, dF, ax0);
     }
+    }  // NONLINEAR preamble
 
     CGM_STAMP(0, 2);
     // ---- Ax_func (cgmres.hpp:164-175) of the direction `dir`: Newton on the trajectory, from the base trajectory
@@ -363,11 +537,22 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(VLDS ?
       // A direction that the rounding of U + h*dir absorbs completely leaves the controls — and with them F — unchanged
       // bit for bit: A*dir = 0 exactly, the reference's breakdown case (gmres.hpp:63-65).  Newton's fixed point agrees
       // with the base trajectory only up to rounding, so that case is answered here.
-      if (__builtin_expect(!__any(in_hor && (u[0] != U[0] || u[1] != U[1] || u[2] != U[2])), 0)) {
+      bool moved = false;
+#pragma unroll
+      for (int j = 0; j < NU; ++j) moved = moved || u[j] != U[j];
+      if (__builtin_expect(!__any(in_hor && moved), 0)) {
 #pragma unroll
         for (int j = 0; j < NU; ++j) out[j] = T(0);
         return;
       }
+      if constexpr (!NONLIN) {
+        T x[NX], phi[NU], dF[NUL], trig[1] = {T(0)};
+        W::state_scan(WL, u, xh, dtau_h, Gh, x);
+        CGM_STAMP(0, 3);
+        backward(x, trig, u, dtau_h, Gh, phi, dF);
+        finish(F_AX, phi, dF, out);
+        CGM_STAMP(0, 5);
+      } else {
       T x0, x2;
       lin_states(u[0], xh, dtau_h, Gh, &x0, &x2);
       const T Pq = M::A32 * x2 * x2, Qq = M::A32a * x2 - M::A32b * u[0];
@@ -418,11 +603,12 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(VLDS ?
         read_tab(2, x, t4);  // (x[0], x[2] stay the scans' values)
         trig[0] = t4[0], trig[1] = t4[1], trig[2] = t4[3];
       }
-      T phi[NU], dF;
+      T phi[NU], dF[NUL];
       CGM_STAMP(0, 12);
-      backward(x, trig, u, dtau_h, Gh, phi, &dF);
+      backward(x, trig, u, dtau_h, Gh, phi, dF);
       finish(F_AX, phi, dF, out);
       CGM_STAMP(0, 5);
+      }  // NONLINEAR
     };
 
     // ---- Gmres::gmres (gmres.hpp:28-112): basis, Hessenberg, reflectors and residual vector all in registers.
@@ -616,8 +802,13 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(VLDS ?
 #pragma unroll
         for (int j = 0; j < NU; ++j) Ug[j] = U[j], dg[j] = du[j], fg[j] = Fh[j];
       }
-      if (lane < NU) P.u_out[size_t(b) * NU + lane] = lane == 0 ? unew[0] : (lane == 1 ? unew[1] : unew[2]);
-      if (lane < NX) P.xdxh[size_t(b) * NX + lane] = lane == 0 ? xh[0] : (lane == 1 ? xh[1] : (lane == 2 ? xh[2] : xh[3]));
+      auto pick = [&](const T* v, int n) {  // element `lane` of a wave-uniform array
+        T r = v[0];
+        for (int q = 1; q < n; ++q) r = lane == q ? v[q] : r;
+        return r;
+      };
+      if (lane < NU) P.u_out[size_t(b) * NU + lane] = pick(unew, NU);
+      if (lane < NX) P.xdxh[size_t(b) * NX + lane] = pick(xh, NX);
       // status + small Krylov arrays (the layout of WgCtx::store_status) + the basis rows in the wg mapping's
       // pair-interleaved form (ctx_wg get_krylov undoes it)
       const int ks_all = k1 * k1 + k1 + 3 * kmax;
@@ -652,12 +843,16 @@ __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(VLDS ?
       }
     }
     if (P.x_next) {  // plant step of the example main loop (<example>/main.cpp:71-73)
-      T f[NX], tr[M::NC];
+      T f[NX], tr[NC > 0 ? NC : 1];
       M::dxdt(f, xs, unew, tr, mc);
 #pragma unroll
       for (int c = 0; c < NX; ++c) xs[c] = xs[c] + f[c] * P.dt;
-      if (last && lane < NX)
-        P.x_next[size_t(b) * NX + lane] = lane == 0 ? xs[0] : (lane == 1 ? xs[1] : (lane == 2 ? xs[2] : xs[3]));
+      if (last && lane < NX) {
+        T r = xs[0];
+#pragma unroll
+        for (int q = 1; q < NX; ++q) r = lane == q ? xs[q] : r;
+        P.x_next[size_t(b) * NX + lane] = r;
+      }
     }
   }
   CGM_STAMP(0, 11);

@@ -189,4 +189,71 @@ __device__ __forceinline__ void scan_aff2_vec(T* c, const Aff2Levels<T>& lv) {
   aff2_step_vec<5>(c, lv.d[5]);
 }
 
+// ---- 4 x 4 affine maps with the SAME matrix in every element (linear time-invariant state / costate equations) ---------
+// y' = y + D y + c_i.  The scan of such elements composes only matrices that are POWERS of M = I + D: step t of an in-row
+// step uses M^(2^t), the two cross-row steps M^((i & 15) + 1) and M^((i & 31) + 1) — all found in one table
+//     pw[n - 1][16] = M^n - I,  n = 1 .. 32   (row-major, this wave's LDS)
+// built once per tick by a matrix-only scan of identical elements over the lanes 0..31 (power_table4), after which every
+// sweep is a VECTOR-only scan: 4 partner values + 16 multiply-adds per step, the matrix read from the table.
+template <class T>
+__device__ __forceinline__ void compose4(T* D, const T* Q) {  // D <- D + Q + D Q
+  T n[16];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      T a = D[4 * r + c] + Q[4 * r + c];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a = fma_t(D[4 * r + k], Q[4 * k + c], a);
+      n[4 * r + c] = a;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) D[e] = n[e];
+}
+template <int STEP, class T>
+__device__ __forceinline__ void power_step4(T* D) {
+  T Q[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) Q[e] = scan_partner<STEP>(D[e]);
+  compose4(D, Q);
+}
+// pw <- powers of I + D0 (D0 wave-uniform); every lane takes part, lanes 0..31 store.  The caller fences before reading.
+template <class T>
+__device__ __forceinline__ void power_table4(T* pw, const T* D0, int lane) {
+  T D[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) D[e] = D0[e];
+  power_step4<0>(D), power_step4<1>(D), power_step4<2>(D), power_step4<3>(D), power_step4<4>(D);
+  if (lane < 32) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) pw[lane * 16 + e] = D[e];
+  }
+}
+template <int STEP, class T>
+__device__ __forceinline__ void const4_step(T* c, const T* D) {
+  T p[4], n[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) p[r] = scan_partner<STEP>(c[r]);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    T a = c[r] + p[r];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a = fma_t(D[4 * r + k], p[k], a);
+    n[r] = a;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c[r] = n[r];
+}
+// c <- the recurrence started from 0 with offsets c (lane i: value after element i), matrices from the table
+template <class T>
+__device__ __forceinline__ void scan_const4(T* c, const T* pw, int lane) {
+  const4_step<0>(c, pw + 0 * 16);          // M^1
+  const4_step<1>(c, pw + 1 * 16);          // M^2
+  const4_step<2>(c, pw + 3 * 16);          // M^4
+  const4_step<3>(c, pw + 7 * 16);          // M^8
+  const4_step<4>(c, pw + (lane & 15) * 16);  // M^((i & 15) + 1)
+  const4_step<5>(c, pw + (lane & 31) * 16);  // M^((i & 31) + 1)
+}
+
 }  // namespace cgm

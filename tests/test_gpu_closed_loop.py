@@ -35,6 +35,10 @@ CASES = {
     "pendulum_B512_wave_fixedk": (0, 50, 10, 0.0, "f64", 512, 4),   # the per-GPU shard of the headline batch at 8 GPUs
     "pendulum_B4096_wave": (0, 50, 10, 1e-6, "f64", 4096, 4),       # the wave mapping oversubscribed (several waves per SIMD / rounds)
     "pendulum_dv25_k5_B67_wave": (0, 25, 5, 1e-6, "f64", 67, 4),    # shipped sizes, ragged batch
+    "semiactive_B512_wave": (2, 50, 10, 1e-6, "f64", 512, 4),       # the wave mapping for a model that is affine in x
+    "semiactive_B300_wave_fixedk": (2, 50, 10, 0.0, "f64", 300, 4),
+    "msd_B512_wave": (1, 50, 10, 1e-6, "f64", 512, 4),              # linear time-invariant: constant-matrix scans (L = 300: 6 elements per lane)
+    "msd_dv20_k5_B33_wave": (1, 20, 5, 0.0, "f64", 33, 4),          # BASELINE configs[0] sizes, ragged batch
     "pendulum_B200_lane": (0, 50, 10, 1e-6, "f64", 200, 1),         # the lane mapping: one tick per launch
     "msd_dv20_k5_B33": (1, 20, 5, 1e-6, "f64", 33, 2),              # ragged batch, shipped-size MSD (IPW rows unused)
 }

@@ -37,7 +37,11 @@ def _teacher_forced(orc, c, refs, x0, ticks, u_tol=U_TOL):
         for i, r in enumerate(refs):
             ur = r.control(x[i])
             worst = max(worst, float(np.max(np.abs(u[i] - ur))))
-            assert np.max(np.abs(u[i] - ur)) <= u_tol, (tick, i, u[i], ur)
+            # u = U + dUdt*dt (cgmres.hpp:102-109): the bound on u that goes with SURVEY 8(c)'s bound on dUdt — relative to
+            # |u| and to dt*|dUdt| where a time jump makes them large (|dUdt| ~ 1e5 on the two-mass system)
+            d_ref = r.get_state()[2]
+            bound = u_tol * max(1.0, float(np.max(np.abs(ur)))) + r.dt * DUDT_REL * max(1.0, float(np.max(np.abs(d_ref))))
+            assert np.max(np.abs(u[i] - ur)) <= bound, (tick, i, u[i], ur)
             k_o, _, reason_o = r.last_solve()
             assert n_ax[i] == k_o and reason[i] == reason_o, (tick, i, n_ax[i], k_o, reason[i], reason_o)
             d_ref = r.get_state()[2]
@@ -55,14 +59,16 @@ def test_the_library_takes_the_wave_mapping_for_batches_smaller_than_the_gpu():
         c = cg.CgmresBatch(**args)
         assert c.variant in (2, 3), (kw, c.variant_name)
         c.close()
-    for model in ("msd", "semiactive"):  # no wave scans for these models (yet): the wg mapping serves them
-        c = cg.CgmresBatch(model, batch=64, dv=50, k_max=10)
-        assert c.variant == 2
-        c.close()
+    c = cg.CgmresBatch("semiactive", batch=64, dv=50, k_max=10)   # affine in x: one 2 x 2 scan per sweep, no Newton
+    assert c.variant == WAVE
+    c.close()
+    c = cg.CgmresBatch("msd", batch=64, dv=50, k_max=10)          # linear time-invariant: constant-matrix scans
+    assert c.variant == WAVE
+    c.close()
     with pytest.raises(cg.CgmresHipError, match="wave mapping"):
         cg.CgmresBatch("pendulum", batch=8, dv=64, k_max=10, variant=WAVE)
     with pytest.raises(cg.CgmresHipError, match="wave mapping"):
-        cg.CgmresBatch("msd", batch=8, dv=20, k_max=5, variant=WAVE)
+        cg.CgmresBatch("msd", batch=8, dv=20, k_max=12, variant=WAVE)
     small.close()
 
 
@@ -87,16 +93,23 @@ def test_every_form_of_the_mat_vec_sweep_vs_oracle(orc, flags, name, tol):
     c.close()
 
 
+@pytest.mark.parametrize("model", [0, 2, 1])
 @pytest.mark.parametrize("dv,km", [(2, 2), (3, 5), (15, 4), (16, 10), (17, 3), (31, 6), (32, 6), (33, 10),
                                     (47, 7), (48, 9), (49, 10), (62, 5), (63, 10)])
-def test_horizon_lengths_at_the_row_boundaries_of_the_scans(orc, dv, km):
+def test_horizon_lengths_at_the_row_boundaries_of_the_scans(orc, dv, km, model):
     """The scans cross DPP rows at lanes 16 / 32 / 48 and the terminal stage sits on lane dv: horizons that end on, just
-    before and just after those lanes, the shortest ones, and the longest the mapping takes (dv = 63)."""
+    before and just after those lanes, the shortest ones, and the longest the mapping takes (dv = 63) — for the pendulum
+    (Newton on the trajectory), the semi-active damper (one 2 x 2 affine scan per sweep) and the two-mass system
+    (constant-matrix 4 x 4 scans from per-tick power tables)."""
     B = 5
-    x0, u0, p = orc.batch_scenario(0, B)
-    c = cg.CgmresBatch("pendulum", batch=B, dv=dv, k_max=km, tol=1e-6, variant=WAVE)
-    c.set_ptau_repeat(p), c.init_u0(u0), c.init_u0_newton(u0, x0, p, 10)
-    refs = _refs(orc, 0, dv, km, 1e-6, x0, u0, p)
+    x0, u0, p = orc.batch_scenario(model, B)
+    if model == 1 and 6 * dv > 320:
+        pytest.skip("dim_u*dv beyond the wg mapping, which serves the white-box hooks of a wave handle")
+    c = cg.CgmresBatch(model, batch=B, dv=dv, k_max=km, tol=1e-6, variant=WAVE)
+    if p.shape[1]:
+        c.set_ptau_repeat(p)
+    c.init_u0(u0), c.init_u0_newton(u0, x0, p if p.shape[1] else None, 10)
+    refs = _refs(orc, model, dv, km, 1e-6, x0, u0, p)
     for r in refs:
         _, U_o, d_o = r.get_state()
         r.set_state(0.7, U_o, d_o)

@@ -29,9 +29,10 @@ def main():
     ap.add_argument("--kmax", type=int, default=10)
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--model", type=int, default=0, help="0 pendulum, 1 msd, 2 semiactive")
     args = ap.parse_args()
     from oracle import orc
-    model = 0
+    model = args.model
     for B in [int(s) for s in args.batches.split(",")]:
         x0, u0, p = orc.batch_scenario(model, B)
         c = cg.CgmresBatch(model, batch=B, dv=args.dv, k_max=args.kmax, tol=args.tol, variant=args.variant,
@@ -39,8 +40,8 @@ def main():
         c.set_ptau_repeat(p)
         c.init_u0(u0)
         c.init_u0_newton(u0, x0, p, 10)
-        xd = c.device_buffer((B, 4))
-        ud = c.device_buffer((B, 3))
+        xd = c.device_buffer((B, c.dim_x))
+        ud = c.device_buffer((B, c.dim_u))
         xd.upload(x0)
         out = {"variant": c.variant, "name": c.variant_name, "B": B, "tol": args.tol}
         if not args.no_check:
