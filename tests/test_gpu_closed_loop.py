@@ -172,8 +172,8 @@ def test_multiple_controller_device_loop_vs_oracle(orc, variant):
     specs = [dict(model="msd", batch=72, dv=dv, k_max=km, variant=variant),
              dict(model="pendulum", batch=88, dv=dv, k_max=km, variant=variant)]
     mc = MultipleController(specs)
-    # (library's choice: the small pendulum member takes the wave mapping, the MSD member the wg mapping)
-    assert [m.variant for m in mc.members] == ([variant, variant] if variant else [2, 4])
+    # (library's choice: such small members both take the wave mapping)
+    assert [m.variant for m in mc.members] == ([variant, variant] if variant else [4, 4])
     xs, us, want = [], [], []
     for m, model in zip(mc.members, (1, 0)):
         x0, u0, p = orc.batch_scenario(model, m.batch)
