@@ -200,7 +200,7 @@ def test_multiple_controller_device_loop_vs_oracle(orc, variant):
 
 
 @pytest.mark.parametrize("per_instance", [True, False])
-@pytest.mark.parametrize("model,variant", [(0, 2), (1, 2), (0, 1), (0, 3), (1, 3)])
+@pytest.mark.parametrize("model,variant", [(0, 2), (1, 2), (0, 1), (0, 3), (1, 3), (0, 4), (1, 4)])
 def test_closed_loop_device_with_moving_reference(orc, model, variant, per_instance):
     """Time-varying reference inside the fused device loop (cgmres_hip_closed_loop_device_ptau): a new parameter
     horizon before every tick == the reference's `set_ptau` (cgmres.hpp:36-39) called before every `control()`.
