@@ -8,7 +8,9 @@ import cgmres_cpp_amd as cg
 from cgmres_cpp_amd import scenarios
 ticks = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 for model, B, dv, km, dtype in [("pendulum", 4096, 50, 10, "f64"), ("msd", 4096, 50, 10, "f64"), ("semiactive", 4096, 50, 10, "f64"),
-                                ("pendulum", 1000, 100, 20, "f32"), ("pendulum", 77, 25, 5, "f64")]:
+                                ("pendulum", 1000, 100, 20, "f32"), ("pendulum", 77, 25, 5, "f64"),
+                                # the wave mapping (library's choice for batches up to two controllers per SIMD)
+                                ("pendulum", 1024, 50, 10, "f64"), ("msd", 512, 50, 10, "f64"), ("semiactive", 512, 50, 10, "f64")]:
     x0, u0, p = scenarios.batch(model, B)
     c = cg.CgmresBatch(model, batch=B, dv=dv, k_max=km, dtype=dtype)  # shipped tol (1e-6): early exits live
     if p.shape[1]: c.set_ptau_repeat(p)
@@ -19,7 +21,7 @@ for model, B, dv, km, dtype in [("pendulum", 4096, 50, 10, "f64"), ("msd", 4096,
     x, u = xd.download(), ud.download()
     n_ax, reason = c.get_status()
     bad = ~(np.isfinite(x).all(axis=1) & np.isfinite(u).all(axis=1))
-    print(f"{model:10s} B={B} dv={dv} k={km} {dtype}: {ticks} ticks in {dt:.2f}s, non-finite instances {np.nonzero(bad)[0].tolist()[:8]}, "
+    print(f"{model:10s} [{c.variant_name}] B={B} dv={dv} k={km} {dtype}: {ticks} ticks in {dt:.2f}s, non-finite instances {np.nonzero(bad)[0].tolist()[:8]}, "
           f"max|x|={np.nanmax(np.abs(x)):.3g} max|u|={np.nanmax(np.abs(u)):.3g}, mean Arnoldi={n_ax.mean():.2f}, exits={np.bincount(reason, minlength=5).tolist()}", flush=True)
     # C/GMRES itself diverges on a few trajectories of the seeded pendulum batch in early-exit mode (the reference does
     # too: DESIGN.md §2); such an instance must carry EXIT_NONFINITE, and they must stay rare
