@@ -248,8 +248,9 @@ __device__ __forceinline__ double lane_select(unsigned long long mask, double a,
   return __hiloint2double(hi, lo);
 }
 
-// VLDS: the Krylov basis lives in LDS instead of registers — the kernel then fits 256 registers and TWO waves share a SIMD
-// (batches beyond one controller per SIMD: their stalls overlap instead of running in rounds)
+// VLDS (experimental, NOT instantiated by the library): the Krylov basis in LDS instead of registers, compiled for two waves
+// per SIMD.  Measured / estimated in DESIGN.md 4.5: capped at 256 registers the pendulum kernel spills 258 VGPRs, and two
+// waves on a SIMD are bound by VALU issue (2 x 17 k instructions x 4 cycles = 58 us per round) — no gain at 4096 controllers.
 template <class M, class T, int KM, int WPB, bool VLDS = false>
 __global__ __launch_bounds__(64 * WPB) __attribute__((amdgpu_waves_per_eu(VLDS ? 2 : 1, VLDS ? 2 : 1))) void tick_wave_kernel(
     WgParams<T> P) {
