@@ -54,6 +54,7 @@ struct CtxWg final : cgmres_hip_ctx {
   // variant 4 ("wave", tick_wave.hip.h): one wavefront per controller; the tick kernel changes, the HBM state, the
   // white-box hooks and everything else of this context stay those of the wg mapping
   bool wave = false;
+  bool row_newton = false;  // wg kernel with WgCtx::NWT = 1
   static constexpr int kWaveKmax = 10, kWaveWpb = 1;
   size_t lds_bytes_tick() const { return wave ? WaveLds<M, T>::bytes(cfg.dv, cfg.k_max, kWaveWpb) : lds_bytes; }
   static bool wave_supported(const cgmres_hip_config& c) {
@@ -63,6 +64,7 @@ struct CtxWg final : cgmres_hip_ctx {
   }
   const char* variant_name() const override {
     if (wave) return "wave";
+    if (row_newton) return "wg+row-newton";
     static const char* const names[2][3] = {{"wg", "wg+parallel-costate", "wg+two-pass-costate"},
                                             {"wg-lean", "wg-lean", "wg-lean+two-pass-costate"}};
     return names[plan == PLAN_LEAN][par_costate];
@@ -208,6 +210,18 @@ struct CtxWg final : cgmres_hip_ctx {
     if constexpr (WaveOps<M>::value && std::is_same<T, double>::value) {
       if (wave) k_tick = tick_wave_kernel<M, T, kWaveKmax, kWaveWpb>;
     }
+    // row-parallel Newton state sweeps (WgCtx::NWT): the full plan's 16-instance kernel with the parallel costate sweep
+    if constexpr (M::HAS_QUAD_SWEEP && std::is_same<T, double>::value) {
+      const size_t extra = size_t(cfg.dv) * NWT_TABX * sizeof(T);
+      if ((cfg.flags & CGMRES_HIP_FLAG_ROW_NEWTON) && !wave && par == 1 && want == 16 && !big && !lean && !fh_hbm &&
+          cfg.dv <= 63 && cfg.k_max <= 12 && lds_bytes + extra <= kLdsLimit &&
+          // (the base trajectory of the Newton sweeps lives in the stage table and the costate-scan scratch during the loop)
+          WgLds<M, T, 16, NWT_TABX>::tab_count(cfg.dv) >= WgCtx<M, T, 16, 10, false, 1, 1>::base_tab_scalars() &&
+          WgLds<M, T, 16>::scan_count(cfg.dv) >= WgCtx<M, T, 16, 10, false, 1, 1>::base_scan_scalars()) {
+        row_newton = true, lds_bytes += extra;
+        k_tick = tick_wg_kernel<M, T, 16, 10, false, 1, 1>;
+      }
+    }
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tick), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 int(lds_bytes_tick())));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hook), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -226,7 +240,7 @@ struct CtxWg final : cgmres_hip_ctx {
     if ((rc = dalloc(&P.U, B * Lg)) || (rc = dalloc(&P.dUdt, B * Lg)) || (rc = dalloc(&P.Fh, B * Lg)) ||
         (rc = dalloc(&P.V, B * k1 * size_t(P.Lv))) || (rc = dalloc(&P.xdxh, B * nx)) ||
         (rc = dalloc(&P.ptau, B * size_t(np) * (cfg.dv + 1))) || (rc = dalloc(&P.kry, B * ks_all)) ||
-        (rc = dalloc(&P.scr, size_t((cfg.batch + ipw - 1) / ipw) * 2 * (cfg.dv + WgLds<M, T, 16>::TAB_PAD) * WgLds<M, T, 16>::NSTG * ipw)) ||
+        (rc = dalloc(&P.scr, size_t((cfg.batch + ipw - 1) / ipw) * 2 * (cfg.dv + WgLds<M, T, 16>::TAB_PAD) * (WgLds<M, T, 16>::NSTG * ipw + NWT_TABX))) ||
         (rc = dalloc(&P.pT, lean ? size_t((cfg.batch + ipw - 1) / ipw) * (cfg.dv + 1) * (np ? np : 1) * ipw : 1)) ||
         (rc = dalloc(&P.park, size_t((cfg.batch + ipw - 1) / ipw) * ipw * P.Lv)) ||  // (every kernel family parks the solution vector now)
         (rc = dalloc(&P.n_ax, B)) || (rc = dalloc(&P.reason, B)) || (rc = dalloc(&x_dev, B * nx)) ||

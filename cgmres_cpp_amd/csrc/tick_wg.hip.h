@@ -37,6 +37,7 @@
 #include <cfloat>
 #include <type_traits>
 
+#include "wave_scan.hip.h"
 #include "dpp.hip.h"
 #include "models.hip.h"
 #include "tick_lane.hip.h"  // sqrt_t / abs_t / FOut
@@ -152,7 +153,7 @@ __device__ __forceinline__ void cgm_stamp_flush() {
 //           per CU overlap.  Chosen when a batch needs more workgroups than the GPU has CUs, or when controllers of
 //           two models share the GPU (multiple_controller).
 enum WgPlan { PLAN_FULL = 0, PLAN_FH_HBM = 1, PLAN_LEAN = 2 };
-template <class M, class T, int IPW>
+template <class M, class T, int IPW, int TABX = 0>  // TABX: spare scalars behind every stage of the stage table (WgCtx::NWT)
 struct WgLds {
   // stage table: NSTG values per (stage, instance), layout [stage][slot][IPW], dv + TAB_PAD stages
   //   after phase 1: slots 0..NSLOT-1 = x(s), trig(s) (model's slot map);  after phase 2: slots 0..NBW-1 = costate coefficients
@@ -163,7 +164,10 @@ struct WgLds {
   T* scan;  // scratch of the chunk-parallel costate sweep (WgCtx::sweep_costate_par), full plans only
   int *flag, *reason, *nax, *ksolve;
   int* binst;  // global instance of every row of this workgroup (WgParams::perm applied)
-  static __host__ __device__ size_t tab_count(int dv) { return size_t(dv + TAB_PAD) * NSTG * IPW; }
+  static __host__ __device__ size_t tab_count(int dv) {
+    if constexpr (TABX != 0) return size_t(dv + TAB_PAD) * (NSTG * IPW + TABX);
+    return size_t(dv + TAB_PAD) * NSTG * IPW;
+  }
   static __host__ __device__ size_t count_T(int dv, int kmax, int Lp, int Pp, int Hp, int plan = PLAN_FULL) {
     const int k1 = kmax + 1;
     const int rows = plan == PLAN_FULL ? 3 : (plan == PLAN_FH_HBM ? 2 : 1);
@@ -230,10 +234,20 @@ struct WgLds {
 // PAR: form of the costate sweep — 0 serial (one lane per instance walks all stages), 1 chunk-parallel with per-stage
 // scratch in LDS (sweep_costate_par: full plans with short vectors), 2 chunk-parallel in two passes, boundary records only
 // (sweep_costate_2pass: every plan).
-template <class M, class T, int IPW, int MAXM, bool LEAN = false, int PAR = 0>
+// NWT = 1: the state sweeps of the Arnoldi loop run as Newton iterations on the whole trajectory, row-parallel on all
+// four waves (row_newton_sweep) instead of the serial quad sweep on wave 0; the stage table then has NWT_TABX spare
+// scalars per stage so that the 16 lanes of a row, which own four consecutive stages each, store into distinct banks.
+constexpr int NWT_TABX = 2;
+template <class M, class T, int IPW, int MAXM, bool LEAN = false, int PAR = 0, int NWT = 0>
 struct WgCtx {
-  using Lds = WgLds<M, T, IPW>;
+  using Lds = WgLds<M, T, IPW, NWT ? NWT_TABX : 0>;
   static constexpr int NSTG = Lds::NSTG;
+  // offset of (stage s, slot) in a stage table
+  static __device__ __forceinline__ int tab_off(int s, int slot = 0) {
+    if constexpr (NWT != 0) return s * TAB_STEP + slot * IPW;
+    return (s * NSTG + slot) * IPW;
+  }
+  static constexpr int TAB_STEP = NSTG * IPW + (NWT ? NWT_TABX : 0);  // scalars from one stage to the next
   const WgParams<T>& P;
   Lds S;
   // lean plan: this row's U in the row layout for the whole launch — in registers, unless a row is 160 bytes per lane or
@@ -326,6 +340,22 @@ struct WgCtx {
       for (int m = 0; m < MAXM; ++m) uu[m] = S.U[inst * P.Lp + elem(m)];
     }
     T* row = S.W + inst * P.Lp;
+    if constexpr (NWT != 0) {
+      // also: did the direction change any control of this row?  One that the rounding of U + h*d absorbs completely
+      // leaves F unchanged bit for bit in the serial sweeps — A*d = 0 exactly, the reference's breakdown case
+      // (gmres.hpp:63-65) — while Newton's fixed point agrees with the serial trajectory up to rounding only: gmres()
+      // answers that case from this flag.
+      bool moved = false;
+      each_elem([&](int m, auto full) {
+        if (decltype(full)::value || elem(m) < P.L) {
+          const T wv = reg[m] * P.h + uu[m];
+          moved = moved || wv != uu[m];
+          row[elem(m)] = wv;
+        }
+      });
+      row_moved = ((__ballot(moved) >> (16 * ((tid >> 4) & 3))) & 0xffffull) != 0;
+      return;
+    }
     each_elem([&](int m, auto full) {  // (see lds_to_reg)
       if (decltype(full)::value || elem(m) < P.L) row[elem(m)] = reg[m] * P.h + uu[m];
     });
@@ -355,6 +385,14 @@ struct WgCtx {
     });
   }
   __device__ __forceinline__ T* vrow(int j) const {  // Krylov vector j of this row's instance
+    if constexpr (NWT != 0) {
+      // From an opaque copy of the instance index at every use: the row addresses are invariant over the whole launch,
+      // and hoisted to the kernel entry they are a dozen 64-bit values in scratch — each reload in the Gram-Schmidt rounds
+      // sits behind s_waitcnt vmcnt(0), i.e. waits for every basis row in flight.
+      int bo = b;
+      asm volatile("" : "+v"(bo));
+      return P.V + (size_t(bo) * (P.kmax + 1) + j) * P.Lv;
+    }
     return P.V + (size_t(b) * (P.kmax + 1) + j) * P.Lv;
   }
   // Krylov rows have pitch 16*MAXM and zero pads (every vector written here has zero pads: lds_to_reg clears
@@ -499,7 +537,7 @@ struct WgCtx {
   template <bool PERT, bool PIPE, bool ALT = false>
   __device__ __forceinline__ void sweep_state(int lane0, const T* x0c, T dtau, T* tab, T* xT, bool only_active) {
     constexpr int NX = M::NX, NU = M::NU, NC = M::NC;
-    constexpr int STEP = NSTG * IPW;
+    constexpr int STEP = TAB_STEP;
     const int dv = P.dv, lt = tid - lane0, CH = chunk_len();
     if (lt < 0 || lt >= 64) return;
     if constexpr (M::HAS_QUAD_SWEEP) {
@@ -741,7 +779,7 @@ struct WgCtx {
     constexpr int NX = M::NX, NU = M::NU, NP = M::NP, NC = M::NC, NBW = M::NBW;
     const T sc_phi = MODE == F_RHS ? P.one_m_zh : T(1.0);
     T x[NX], tr[NC > 0 ? NC : 1], u[NU], p[NP > 0 ? NP : 1], bw[NBW], phi[NU];
-    const T* Rs = tab + (s * NSTG) * IPW + i;
+    const T* Rs = tab + tab_off(s) + i;
 #pragma unroll
     for (int c = 0; c < NX; ++c) x[c] = Rs[c * IPW];
     if constexpr (ALT_X02) {
@@ -760,7 +798,7 @@ struct WgCtx {
     // x/trig precede these writes in program order.
     static_assert(NBW % 2 == 0 && (IPW * 16) % 64 == 0, "pair-interleaved costate coefficients");
     {
-      Pair* Rp = reinterpret_cast<Pair*>(S.R + (s * NSTG) * IPW) + i;
+      Pair* Rp = reinterpret_cast<Pair*>(S.R + tab_off(s)) + i;
 #pragma unroll
       for (int c = 0; c < NBW; c += 2) Rp[(c / 2) * IPW] = Pair{bw[c], bw[c + 1]};
     }
@@ -824,7 +862,7 @@ struct WgCtx {
     for (int g = 0; g < COEFF_GROUP; ++g) {
       const int q = q0 + g * stride, i = q & (IPW - 1), s = s0 + 2 * (q / IPW);
       if (q < n_items && item_on(i, only_active)) {
-        T x02[2] = {S.R[(s * NSTG + M::QSLOT_XA) * IPW + i], S.R[(s * NSTG + M::QSLOT_XB) * IPW + i]};
+        T x02[2] = {S.R[tab_off(s, M::QSLOT_XA) + i], S.R[tab_off(s, M::QSLOT_XB) + i]};
         const T u0 = (PERT || LEAN ? S.W : S.U)[i * P.Lp + s * M::NU];
         coeff_item<PERT, MODE>(s, i, dtau, S.R, out, &pre[g][0]);
         if (s + 1 < s_end) {
@@ -875,7 +913,7 @@ struct WgCtx {
           const int l = lt & 63, i = l & (IPW - 1), half = l >> 5;
           const int ps = s0 + 2 * (2 * (lt >> 6) + ((l >> 4) & 1)), st = ps + half;
           if (st < s0 + n && item_on(i, only_active)) {
-            T x02[2] = {S.R[(ps * NSTG + M::QSLOT_XA) * IPW + i], S.R[(ps * NSTG + M::QSLOT_XB) * IPW + i]};
+            T x02[2] = {S.R[tab_off(ps, M::QSLOT_XA) + i], S.R[tab_off(ps, M::QSLOT_XB) + i]};
             const T u0 = (PERT || LEAN ? S.W : S.U)[i * P.Lp + ps * M::NU];
             T x0n = x02[0], x2n = x02[1];
             M::x02_step(x0n, x2n, u0, dtau);
@@ -887,7 +925,7 @@ struct WgCtx {
         for (int q = lt; q < ((n + 1) >> 1) * IPW; q += NL) {  // items = (stage pair, instance)
           const int i = q & (IPW - 1), s = s0 + 2 * (q / IPW);
           if (!item_on(i, only_active)) continue;
-          T x02[2] = {S.R[(s * NSTG + M::QSLOT_XA) * IPW + i], S.R[(s * NSTG + M::QSLOT_XB) * IPW + i]};
+          T x02[2] = {S.R[tab_off(s, M::QSLOT_XA) + i], S.R[tab_off(s, M::QSLOT_XB) + i]};
           const T u0 = (PERT || LEAN ? S.W : S.U)[i * P.Lp + s * M::NU];
           coeff_item<PERT, MODE>(s, i, dtau, S.R, out);
           if (s + 1 < s0 + n) {
@@ -949,7 +987,7 @@ struct WgCtx {
     constexpr int opitch = HOM ? NUL * HL : NU;    // and between stages
     static_assert(NLOAD % 2 == 0, "coefficients are fetched in pairs");
     const T sc = MODE == F_PLAIN ? T(1.0) : (MODE == F_RHS ? P.one_m_zh * P.inv_h : P.inv_h);
-    constexpr int STEP = NSTG * IPW;
+    constexpr int STEP = TAB_STEP;
     struct Ops {
       T bw[NBW], o[NUL];
     };
@@ -1391,6 +1429,10 @@ struct WgCtx {
       __threadfence_block();
       __syncthreads();  // drains vmcnt: the HBM tables are complete and visible to the other waves of this CU
       CGM_STAMP(*this, 4);
+      if constexpr (NWT != 0) {
+        capture_base();
+        __syncthreads();  // the table has been read before the coefficients overwrite it
+      }
       sweep_coeffs<false, F_PLAIN>(dtau_h, S.R, S.Fh, false);  // (S.Fh is S.W itself when fh_hbm)
       __syncthreads();
       CGM_STAMP(*this, 5);
@@ -1442,12 +1484,375 @@ struct WgCtx {
   template <class After, class Idle>
   __device__ __forceinline__ void ax(bool only_active, After&& after_sweep, Idle&& idle_work) {
     CGM_STAMP(*this, 3);
-    f_eval<true, F_AX>(S.xh, dtau_h, S.W, only_active, after_sweep, idle_work);
+    if constexpr (NWT != 0) {
+      if (tid >= 64) idle_work();
+      row_newton_sweep<F_AX>(dtau_h, S.W, only_active);
+      CGM_STAMP(*this, 4);
+    } else {
+      f_eval<true, F_AX>(S.xh, dtau_h, S.W, only_active, after_sweep, idle_work);
+    }
     __syncthreads();
     CGM_STAMP(*this, 6);
   }
   __device__ __forceinline__ void ax(bool only_active) {
     ax(only_active, [] {}, [] {});
+  }
+
+  // ---- NWT = 1: the perturbed state sweeps as Newton on the whole trajectory, row-parallel ----------------------------
+  // The serial state sweep (sweep_state) keeps ONE wave busy for ~12 k cycles per mat-vec while the others mostly wait
+  // (profiles/r04_wg_instruction_counters.json: 23 % of the VALU issue slots used).  Here every row of 16 lanes solves its
+  // own instance's recurrence cgmres.hpp:132-140 for ALL stages at once, on all four waves:
+  //   * lane r of the row owns the stages 4r .. 4r+3 (dv <= 63);
+  //   * x0 / x2 (model.hpp:38,40: linear, no trig) as the DIFFERENCE to the unperturbed trajectory — a scan of the
+  //     control differences with powers of the constant 2 x 2 matrix, four in-row DPP steps;
+  //   * x1 / x3 by Newton's method on the stage equations, started from the unperturbed trajectory (the direction is
+  //     scaled by h = 1e-3..: the perturbed trajectory is close): per iteration the stage residuals, the local
+  //     composition of the lane's four linearised stage maps, one in-row scan of 2 x 2 affine maps (wave_scan.hip.h),
+  //     and the local expansion; sin / cos by rotation of the base values (fresh evaluation when an angle moved too
+  //     far).  Quadratic convergence: the loop ends when a correction is below 1e-10 relative, i.e. the next one would
+  //     be below rounding; measured two iterations per mat-vec.
+  // The base trajectory (x, sin/cos per owned stage: 32 values per lane) is taken from the stage table of the tick's
+  // first unperturbed sweep (preamble), which stays the serial quad sweep.  The result differs from the serial sweep's
+  // by rounding only (tests/test_gpu_parity.py bounds it against the oracle like every other mapping).
+  static constexpr bool ROW_NEWTON = NWT == 1;
+  static constexpr int SPL = 4, NEWTON_MAX = 8;
+  struct RowBase {
+    T x0[SPL], x1[SPL], x2[SPL], sd[SPL], cd[SPL], s1[SPL], c1[SPL];
+  };
+  static constexpr int NBASE = 7;  // arrays of RowBase
+  struct NoBase {};
+  std::conditional_t<ROW_NEWTON, RowBase, NoBase> nb;
+  mutable bool row_moved = true;  // the published direction changed at least one control of this row (publish_direction)
+  // call after the preamble's sweep #1 has left x / trig in S.R and x(dv) in S.xT, before its coefficients overwrite them
+  __device__ __forceinline__ void capture_base() {
+    const int dv = P.dv;
+    T x1n[SPL + 1];
+#pragma unroll
+    for (int q = 0; q <= SPL; ++q) {
+      const int s = SPL * r + q;
+      T v = S.R[tab_off(s < dv ? s : 0, 1) + inst];
+      if (s == dv) v = S.xT[1 * IPW + inst];
+      x1n[q] = s <= dv ? v : T(0);
+    }
+#pragma unroll
+    for (int q = 0; q < SPL; ++q) {
+      const int s = SPL * r + q, sc = s < dv ? s : 0;
+      T x0 = S.R[tab_off(sc, M::QSLOT_XA) + inst], x2 = S.R[tab_off(sc, M::QSLOT_XB) + inst];
+      if (s == dv) x0 = S.xT[0 * IPW + inst], x2 = S.xT[2 * IPW + inst];
+      if (s > dv) x0 = T(0), x2 = T(0);
+      nb.x0[q] = x0, nb.x1[q] = x1n[q], nb.x2[q] = x2;
+      mc.sincos_pair(x0 - x1n[q], x1n[q], &nb.sd[q], &nb.cd[q], &nb.s1[q], &nb.c1[q]);
+    }
+  }
+  // During the Arnoldi loop the base lives in LDS — in the stage table and the costate-scan scratch, which only the
+  // preamble uses (ctx_wg checks that they are large enough) — as pairs [array][q / 2][thread]: every lane reads back
+  // exactly what it wrote (no barrier), 16 bytes per access, conflict-free.  Call after the preamble's last barrier.
+  __device__ __forceinline__ Pair* base_pairs(int k, int thread) const {
+    constexpr int PER = (SPL / 2) * IPW * 16;  // pairs per array
+    return reinterpret_cast<Pair*>(k < 4 ? S.R : S.scan) + (k < 4 ? k : k - 4) * PER + thread;
+  }
+  static constexpr size_t base_tab_scalars() { return size_t(4) * SPL * IPW * 16; }   // needed in the stage table
+  static constexpr size_t base_scan_scalars() { return size_t(NBASE - 4) * SPL * IPW * 16; }  // and in the scan scratch
+  __device__ __forceinline__ void store_base() {
+    const T* src[NBASE] = {nb.x0, nb.x1, nb.x2, nb.sd, nb.cd, nb.s1, nb.c1};
+#pragma unroll
+    for (int k = 0; k < NBASE; ++k) {
+      Pair* d = base_pairs(k, tid);
+#pragma unroll
+      for (int q = 0; q < SPL; q += 2) d[(q / 2) * IPW * 16] = Pair{src[k][q], src[k][q + 1]};
+    }
+    inv_dtau_nb = T(1) / dtau_h;
+  }
+  __device__ __forceinline__ void load_base(int k, T* dst, int thread) const {
+    const Pair* d = base_pairs(k, thread);
+#pragma unroll
+    for (int q = 0; q < SPL; q += 2) {
+      const Pair t = d[(q / 2) * IPW * 16];
+      dst[q] = t.a, dst[q + 1] = t.b;
+    }
+  }
+  T inv_dtau_nb = T(0);
+  // sin / cos of (base angle + dl) from the base pair, |dl| <= sqrt(rot_zmax)
+  __device__ __forceinline__ void rotate(T sb, T cb, T dl, T* sn_out, T* cs_out) const {
+    constexpr int NRS = decltype(mc)::NRS, NRC = decltype(mc)::NRC;
+    const T z = dl * dl;
+    T ps = mc.rot_sin(NRS - 1), pc = mc.rot_cos(NRC - 1);
+#pragma unroll
+    for (int i = NRS - 2; i >= 0; --i) ps = fma_t(z, ps, mc.rot_sin(i));
+#pragma unroll
+    for (int i = NRC - 2; i >= 0; --i) pc = fma_t(z, pc, mc.rot_cos(i));
+    const T sn = fma_t(z * dl, ps, dl);  // sin dl
+    const T cm1 = z * pc;                // cos dl - 1
+    *sn_out = sb + fma_t(sb, cm1, cb * sn);
+    *cs_out = cb + fma_t(cb, cm1, -(sb * sn));
+  }
+  // F(U + h d, x + h f, t + h) - F(U, x + h f, t + h), / h, for the row's instance (W holds U + h d on entry, the
+  // result on exit): state recurrence, costate recurrence and dH/du all in the registers of the row's 16 lanes — no
+  // stage table, no workgroup barrier; the only LDS traffic is the row's own operands (W, U, F(U,x+hf,t+h), ptau).
+  // COLLECTIVE over the wave (wave-uniform branches on __any).
+  // Stages outside the horizon (s >= dv; the last lanes of the row) are IDENTITY maps by construction — their step
+  // sizes and coefficients are zeroed once per sweep — so the folds and expansions below carry no per-stage selects.
+  template <int MODE>
+  __device__ __forceinline__ void row_newton_sweep(T dtau, T* out, bool only_active) {
+    constexpr int NU = M::NU, NP = M::NP, NBW = M::NBW;
+    static_assert(MODE == F_AX, "only the mat-vec of the Arnoldi loop");
+    static_assert(NU == 3 && NP == 2 && M::NUL == 1, "written for the pendulum's stage");
+    // (everything below derives from the thread index and is invariant over sweeps and ticks: left visible, the compiler
+    // hoists it to the top of the kernel and keeps dozens of values alive across the Gram-Schmidt rounds — in scratch,
+    // reloaded behind s_waitcnt vmcnt(0), i.e. behind the basis rows in flight)
+    int tid_o = tid;
+    asm volatile("" : "+v"(tid_o));
+    const int r = tid_o & 15, inst = tid_o >> 4;
+    const int dv = P.dv, s_0 = SPL * r;
+    const bool run = valid && (!only_active || S.flag[inst] != 0);
+    const T* Wr = S.W + inst * P.Lp;
+    const T* Ur = S.U + inst * P.Lp;
+    const T ee = -dtau * M::C22;
+    bool tr[SPL];            // stage s_0 + q has a transition (s < dv)
+    T dq[SPL], eq[SPL];      // its step sizes: dtau, -dtau C22, or 0
+    T u0[SPL], du[SPL];
+#pragma unroll
+    for (int q = 0; q < SPL; ++q) {
+      tr[q] = s_0 + q < dv;
+      dq[q] = tr[q] ? dtau : T(0), eq[q] = tr[q] ? ee : T(0);
+      const int e = tr[q] ? (s_0 + q) * NU : 0;
+      u0[q] = Wr[e];
+      du[q] = tr[q] ? u0[q] - Ur[e] : T(0);
+    }
+    const int q_term = dv - s_0;                       // local index of "stage dv" (the terminal state), if in 0..SPL-1
+    const bool has_term = q_term >= 0 && q_term < SPL;
+    // ---- x0, x2: difference to the base trajectory (zero initial difference)
+    const T a = T(1) - dtau * M::As, bs = dtau * M::Bs;
+    T dx0[SPL], dx2[SPL];
+    {
+      T e0 = T(0), e2 = T(0);
+#pragma unroll
+      for (int q = 0; q < SPL; ++q) {
+        const T n0 = fma_t(dtau, e2, e0);
+        e2 = fma_t(a, e2, bs * du[q]);
+        e0 = n0;
+      }
+      const T a2 = a * a;
+      T m11 = a2 * a2, m01 = dtau * ((T(1) + a) + (a2 + a * a2));  // the lane's four stages: [[1, m01], [0, m11]]
+      auto step = [&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        const T p0 = scan_partner<t>(e0), p2 = scan_partner<t>(e2);
+        e0 = (e0 + p0) + m01 * p2;
+        e2 = fma_t(m11, p2, e2);
+        m01 = fma_t(m01, m11, m01);
+        m11 = m11 * m11;
+      };
+      step(std::integral_constant<int, 0>{}), step(std::integral_constant<int, 1>{});
+      step(std::integral_constant<int, 2>{}), step(std::integral_constant<int, 3>{});
+      T x0 = scan_partner<0>(e0), x2 = scan_partner<0>(e2);  // the state the lane's first stage starts from
+#pragma unroll
+      for (int q = 0; q < SPL; ++q) {
+        dx0[q] = x0, dx2[q] = x2;
+        const T n0 = fma_t(dtau, x2, x0);
+        x2 = fma_t(a, x2, bs * du[q]);
+        x0 = n0;
+      }
+    }
+    CGM_STAMP(*this, 21);
+    // ---- x1, x3: Newton.  The trig values are carried from iteration to iteration by rotation: first by the change of
+    //      x0 (y1 starts at the base value), then by the corrections of y1.
+    T x0f[SPL], x2f[SPL], Pq[SPL], Qq[SPL], y1[SPL], y3[SPL], sd[SPL], cd[SPL], s1[SPL], c1[SPL];
+    {
+      T b0[SPL], b2[SPL];
+      load_base(0, b0, tid_o), load_base(2, b2, tid_o), load_base(1, y1, tid_o);
+      load_base(3, sd, tid_o), load_base(4, cd, tid_o), load_base(5, s1, tid_o), load_base(6, c1, tid_o);
+#pragma unroll
+      for (int q = 0; q < SPL; ++q) {
+        x0f[q] = b0[q] + dx0[q], x2f[q] = b2[q] + dx2[q];
+        Pq[q] = M::A32 * x2f[q] * x2f[q];
+        Qq[q] = M::A32a * x2f[q] - M::A32b * u0[q];
+      }
+      // x3 is not part of the base: x3(s) = (x1(s+1) - x1(s)) / dtau of the base trajectory (a starting value only)
+      const T yb = dpp_row_zero_fill<0x101>(y1[0]);  // row_shl:1
+#pragma unroll
+      for (int q = 0; q < SPL; ++q)
+        y3[q] = tr[q] ? ((q + 1 < SPL ? y1[q + 1 < SPL ? q + 1 : 0] : yb) - y1[q]) * inv_dtau_nb : T(0);
+    }
+    T ad[SPL], a1[SPL];  // angle increments since the trig values were last brought up to date: of x0 - x1, of x1
+#pragma unroll
+    for (int q = 0; q < SPL; ++q) ad[q] = dx0[q], a1[q] = T(0);
+    const T rmax = T(0.9) * sqrt_t<T>(T(decltype(mc)::rot_zmax));
+    const int n_it = (P.wave_dbg & 2) ? 0 : NEWTON_MAX;
+    for (int it = 0; it < n_it; ++it) {
+      T jq[SPL], c0q[SPL], c1q[SPL];
+      T amax = T(0);  // (stages outside the horizon carry harmless finite values)
+#pragma unroll
+      for (int q = 0; q < SPL; ++q) amax = __builtin_fmax(amax, __builtin_fmax(abs_t(ad[q]), abs_t(a1[q])));
+      if (__builtin_expect((P.wave_dbg & 1) || __any(run && !(amax <= rmax)), 0)) {
+#pragma unroll
+        for (int q = 0; q < SPL; ++q) mc.sincos_pair(x0f[q] - y1[q], y1[q], &sd[q], &cd[q], &s1[q], &c1[q]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < SPL; ++q) rotate(sd[q], cd[q], ad[q], &sd[q], &cd[q]);
+        if (it > 0) {
+#pragma unroll
+          for (int q = 0; q < SPL; ++q) rotate(s1[q], c1[q], a1[q], &s1[q], &c1[q]);
+        }
+      }
+      // defects of the stage equations (the stage after the lane's last one belongs to the next lane) and the local
+      // composition of the linearised stage maps  D -> D + [[0, dq], [j, eq]] (I + D)  in the D-form of wave_scan.hip.h
+      const T yn1 = dpp_row_zero_fill<0x101>(y1[0]), yn3 = dpp_row_zero_fill<0x101>(y3[0]);  // row_shl:1
+      T D[4] = {T(0), T(0), T(0), T(0)}, c[2] = {T(0), T(0)};
+#pragma unroll
+      for (int q = 0; q < SPL; ++q) {
+        // model.hpp:41 and its derivative in x1
+        const T g = fma_t(Pq[q], sd[q], fma_t(M::A52, s1[q], fma_t(Qq[q], cd[q], M::C22 * (x2f[q] - y3[q]))));
+        const T J1 = fma_t(Qq[q], sd[q], fma_t(M::A52, c1[q], -(Pq[q] * cd[q])));
+        const T t1 = fma_t(dtau, y3[q], y1[q]), t3 = fma_t(dtau, g, y3[q]);
+        jq[q] = dq[q] * J1;
+        const T r1 = t1 - (q + 1 < SPL ? y1[q + 1 < SPL ? q + 1 : 0] : yn1);
+        const T r3 = t3 - (q + 1 < SPL ? y3[q + 1 < SPL ? q + 1 : 0] : yn3);
+        c0q[q] = tr[q] ? r1 : T(0), c1q[q] = tr[q] ? r3 : T(0);
+        const T n00 = fma_t(dq[q], D[2], D[0]);
+        const T n01 = fma_t(dq[q], D[3], D[1] + dq[q]);
+        const T n10 = fma_t(eq[q], D[2], fma_t(jq[q], D[0], D[2] + jq[q]));
+        const T n11 = fma_t(eq[q], D[3], fma_t(jq[q], D[1], D[3] + eq[q]));
+        const T m0 = fma_t(dq[q], c[1], c[0] + c0q[q]);
+        const T m1 = fma_t(eq[q], c[1], fma_t(jq[q], c[0], c[1] + c1q[q]));
+        D[0] = n00, D[1] = n01, D[2] = n10, D[3] = n11, c[0] = m0, c[1] = m1;
+      }
+      aff2_step_vec<0>(c, D), aff2_step_mat<0>(D);
+      aff2_step_vec<1>(c, D), aff2_step_mat<1>(D);
+      aff2_step_vec<2>(c, D), aff2_step_mat<2>(D);
+      aff2_step_vec<3>(c, D);
+      T e1 = scan_partner<0>(c[0]), e3 = scan_partner<0>(c[1]);  // correction of the lane's first stage
+      T viol = T(-1);
+      T dl1[SPL];
+      const T th = T(1e-10);
+#pragma unroll
+      for (int q = 0; q < SPL; ++q) {
+        y1[q] += e1, y3[q] += e3;
+        dl1[q] = e1, ad[q] = -e1, a1[q] = e1;
+        const T vq = __builtin_fmax(abs_t(e1) - th * (T(1) + abs_t(y1[q])), abs_t(e3) - th * (T(1) + abs_t(y3[q])));
+        viol = s_0 + q <= dv ? __builtin_fmax(viol, vq) : viol;  // (beyond stage dv its correction is carried on unchanged)
+        const T n1 = fma_t(dq[q], e3, e1 + c0q[q]);
+        const T n3 = fma_t(eq[q], e3, fma_t(jq[q], e1, e3 + c1q[q]));
+        e1 = n1, e3 = n3;
+      }
+      CGM_STAMP(*this, 22);
+      if (!__any(run && viol > T(0))) {
+        // the correction is below the square root of the rounding level: trig values to first order, done
+#pragma unroll
+        for (int q = 0; q < SPL; ++q) {
+          const T nsd = fma_t(cd[q], -dl1[q], sd[q]), ncd = fma_t(sd[q], dl1[q], cd[q]);
+          const T ns1 = fma_t(c1[q], dl1[q], s1[q]), nc1 = fma_t(s1[q], -dl1[q], c1[q]);
+          sd[q] = nsd, cd[q] = ncd, s1[q] = ns1, c1[q] = nc1;
+        }
+        break;
+      }
+    }
+    // ---- costate (cgmres.hpp:145-153) and dH/du (:156-161) of the owned stages: the backward recurrence
+    //      PendulumDev::costate_step is affine in the costate with (l1, l3) closed in themselves, l0 a running sum over
+    //      l3 and l2 a geometric recurrence over l0 / l3 — three scans DOWN the row (partner = the lane above), each as
+    //      local fold, in-row scan, local expansion.  The terminal costate (cgmres.hpp:143) is the starting value of
+    //      the lane that holds stage dv (nothing above it but identities).
+    T bw[SPL][NBW], phi0[SPL];
+    T lT[M::NX] = {T(0), T(0), T(0), T(0)};
+    {
+      T u1[SPL], u2[SPL], pp[SPL][NP], fh[SPL][NU];
+#pragma unroll
+      for (int q = 0; q < SPL; ++q) {  // every LDS operand first (addresses clamped into the horizon: no branch, one wait)
+        const int s = s_0 + q, sc = s < dv ? s : dv - 1, sp = s < dv ? s : dv;
+        u1[q] = Wr[sc * NU + 1], u2[q] = Wr[sc * NU + 2];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) pp[q][j] = get_p(inst, sp * NP + j);
+#pragma unroll
+        for (int j = 0; j < NU; ++j) fh[q][j] = S.Fh[inst * P.Lp + sc * NU + j];
+      }
+#pragma unroll
+      for (int q = 0; q < SPL; ++q) {
+        const int s = s_0 + q;
+        const T x[M::NX] = {x0f[q], y1[q], x2f[q], y3[q]};
+        const T tg[3] = {sd[q], cd[q], c1[q]}, u[NU] = {u0[q], u1[q], u2[q]};
+        T phi[NU], bq[NBW];
+        M::stage_coeffs(bq, phi, x, u, pp[q], tg, dtau);
+#pragma unroll
+        for (int cc = 0; cc < NBW; ++cc) bw[q][cc] = tr[q] ? bq[cc] : T(0);
+        phi0[q] = (phi[0] - fh[q][0]) * P.inv_h;
+        if (run && tr[q]) {
+          out[inst * P.Lp + s * NU + 1] = (phi[1] - fh[q][1]) * P.inv_h;
+          out[inst * P.Lp + s * NU + 2] = (phi[2] - fh[q][2]) * P.inv_h;
+        }
+        if (q == q_term) M::dPhidx(lT, x, pp[q]);
+      }
+    }
+    CGM_STAMP(*this, 24);
+    T L0[SPL], L2[SPL], L3[SPL];  // costate components ENTERING the owned stages (lambda of stage s + 1)
+    {
+      // (l1, l3): n1 = l1 + bw1 l3 + bw5,  n3 = l3 + dq l1 + eq l3; the lane with stage dv starts from the constant map
+      T D[4] = {has_term ? T(-1) : T(0), T(0), T(0), has_term ? T(-1) : T(0)};
+      T c[2] = {has_term ? lT[1] : T(0), has_term ? lT[3] : T(0)};
+#pragma unroll
+      for (int q = SPL - 1; q >= 0; --q) {
+        const T b1 = bw[q][1];
+        const T n00 = fma_t(b1, D[2], D[0]);
+        const T n01 = fma_t(b1, D[3], D[1] + b1);
+        const T n10 = fma_t(eq[q], D[2], fma_t(dq[q], D[0], D[2] + dq[q]));
+        const T n11 = fma_t(eq[q], D[3], fma_t(dq[q], D[1], D[3] + eq[q]));
+        const T m0 = fma_t(b1, c[1], c[0] + bw[q][5]);
+        const T m1 = fma_t(eq[q], c[1], fma_t(dq[q], c[0], c[1]));
+        D[0] = n00, D[1] = n01, D[2] = n10, D[3] = n11, c[0] = m0, c[1] = m1;
+      }
+      aff2_step_vec<0, true>(c, D), aff2_step_mat<0, true>(D);
+      aff2_step_vec<1, true>(c, D), aff2_step_mat<1, true>(D);
+      aff2_step_vec<2, true>(c, D), aff2_step_mat<2, true>(D);
+      aff2_step_vec<3, true>(c, D);
+      // costate entering the lane's last stage (the lanes above the one with stage dv deliver zeros)
+      T l1 = scan_partner<0, true>(c[0]), l3 = scan_partner<0, true>(c[1]);
+      l1 = has_term ? lT[1] : l1, l3 = has_term ? lT[3] : l3;
+      T l0s = has_term ? lT[0] : T(0);  // l0 relative to the lane's entry: n0 = l0 + (bw4 + bw0 l3)
+#pragma unroll
+      for (int q = SPL - 1; q >= 0; --q) {
+        L3[q] = l3, L0[q] = l0s;
+        l0s += fma_t(bw[q][0], l3, bw[q][4]);
+        const T n1 = fma_t(bw[q][1], l3, l1 + bw[q][5]);
+        const T n3 = fma_t(eq[q], l3, fma_t(dq[q], l1, l3));
+        l1 = n1, l3 = n3;
+      }
+      T t0 = l0s;
+      t0 += scan_partner<0, true>(t0);
+      t0 += scan_partner<1, true>(t0);
+      t0 += scan_partner<2, true>(t0);
+      t0 += scan_partner<3, true>(t0);
+      const T in0 = scan_partner<0, true>(t0);
+      // l2: n2 = aq l2 + (bw2 l3 + dq l0), aq = 1 - dq As
+      T e2 = has_term ? lT[2] : T(0);
+#pragma unroll
+      for (int q = SPL - 1; q >= 0; --q) {
+        L0[q] += in0;
+        e2 = fma_t(fma_t(-M::As, dq[q], T(1)), e2, fma_t(bw[q][2], L3[q], dq[q] * L0[q]));
+      }
+      {
+        const T a2 = a * a;
+        T m = a2 * a2;  // (a lane with fewer than four stages has nothing but zeros above it: its multiplier is not used)
+        e2 = fma_t(m, scan_partner<0, true>(e2), e2), m = m * m;
+        e2 = fma_t(m, scan_partner<1, true>(e2), e2), m = m * m;
+        e2 = fma_t(m, scan_partner<2, true>(e2), e2), m = m * m;
+        e2 = fma_t(m, scan_partner<3, true>(e2), e2);
+      }
+      T l2 = scan_partner<0, true>(e2);
+      l2 = has_term ? lT[2] : l2;
+#pragma unroll
+      for (int q = SPL - 1; q >= 0; --q) {
+        L2[q] = l2;
+        l2 = fma_t(fma_t(-M::As, dq[q], T(1)), l2, fma_t(bw[q][2], L3[q], dq[q] * L0[q]));
+      }
+    }
+    if (run) {
+#pragma unroll
+      for (int q = 0; q < SPL; ++q) {
+        if (tr[q]) {
+          const T dF = fma_t(bw[q][3], L3[q], L2[q] * M::Bs);  // B^T lambda, costate_step
+          out[inst * P.Lp + (s_0 + q) * NU] = fma_t(dF, P.inv_h, phi0[q]);
+        }
+      }
+    }
+    CGM_STAMP(*this, 23);
   }
 
   // Hessenberg column k of one instance: stored reflectors, new reflector, residual rotation (gmres.hpp:71-90) — scalar
@@ -1520,7 +1925,7 @@ struct WgCtx {
     // Gram-Schmidt rounds are bounded by the CU's 64 B/clk vector-memory path, not by issue.  The ring then serves the
     // rows from NKEEP on.  Pays for itself only where registers are left: the one-workgroup-per-CU kernels with short
     // vectors, with the solution vector parked in HBM for the duration of the loop like the long-vector kernels do.
-    constexpr int NKEEP = (!LEAN && MAXM <= 10) ? 2 : 0;
+    constexpr int NKEEP = (!LEAN && MAXM <= 10 && NWT == 0) ? 2 : 0;  // (NWT: the Newton sweep needs the registers)
     T vkeep[NKEEP > 0 ? NKEEP : 1][MAXM];
     // workgroup-uniform; longer bases use the plain streaming loop.  So does the lean plan: with 256 registers per wave the
     // twelve straight-line copies of the rounds push everything that lives across them (U, the sweep constants) into
@@ -1531,7 +1936,7 @@ struct WgCtx {
     // push the Gram-Schmidt rounds into AGPR copies and scratch (profiles/r02_isa_summary.md).  Park it in HBM
     // (own row, same thread writes and reads it back: program order) and fetch it back behind the back substitution.
     T* const park_row = P.park + size_t(blockIdx.x * IPW + inst) * P.Lv;
-    constexpr bool PARK = MAXM > 10 || (LEAN && sizeof(T) == 8) || NKEEP > 0;  // (lean fp64: 256 registers per wave)
+    constexpr bool PARK = MAXM > 10 || (LEAN && sizeof(T) == 8) || NKEEP > 0 || NWT != 0;  // (lean fp64: 256 registers per wave)
     if constexpr (PARK) store_vec(park_row, xv);
     // r0 = b - A x0 ; rho = ||r0||      gmres.hpp:33-37
     {
@@ -1612,7 +2017,7 @@ struct WgCtx {
             if (i + NKEEP < k) load_vec(vbuf[i], vrow(i + NKEEP));
         }
       };
-      if (tid >= 64) request_rows();
+      if (NWT != 0 || tid >= 64) request_rows();  // (NWT: no serial sweep to keep clear of — every wave asks now)
       auto deferred_column = [&]() {  // column k-1 of instance j = tid-64, if iteration k-1 produced one for it
         const int j = tid - 64;
         if (defer_hess && k > 0 && j >= 0 && j < IPW && S.reason[j] == 0 && S.nax[j] == k) {
@@ -1623,6 +2028,12 @@ struct WgCtx {
       ax(true, request_rows, deferred_column);  // :48  W <- A v_k, in place
       if (active) {
         lds_to_reg(w, S.W);
+        if constexpr (NWT != 0) {
+          if (!row_moved) {  // (see publish_direction)
+#pragma unroll
+            for (int m = 0; m < MAXM; ++m) w[m] = T(0);
+          }
+        }
         T* Hk = Hi + hoff(k);
         // modified Gram-Schmidt, gmres.hpp:52-58, in order; v_k itself is still in registers
         auto mgs_round = [&](const T* vi, int i) {
@@ -1890,11 +2301,11 @@ struct WgCtx {
 };
 
 // ---- the tick kernel: cgmres.hpp:78-110 for IPW instances ----------------------------------------
-template <class M, class T, int IPW, int MAXM, bool LEAN = false, int PAR = 0>
+template <class M, class T, int IPW, int MAXM, bool LEAN = false, int PAR = 0, int NWT = 0>
 __global__ __launch_bounds__(IPW * 16) __attribute__((amdgpu_waves_per_eu(LEAN ? 2 : 1, LEAN ? 2 : 1))) void tick_wg_kernel(
     WgParams<T> P) {
   extern __shared__ __align__(16) unsigned char smem[];
-  WgCtx<M, T, IPW, MAXM, LEAN, PAR> C(P, smem);
+  WgCtx<M, T, IPW, MAXM, LEAN, PAR, NWT> C(P, smem);
   T du[MAXM], bb[MAXM];
   C.load_common(P.U);
   C.load_row_to_reg(du, P.dUdt, P.Lg);
@@ -1910,6 +2321,7 @@ __global__ __launch_bounds__(IPW * 16) __attribute__((amdgpu_waves_per_eu(LEAN ?
     if constexpr (!LEAN) C.publish_direction(du);  // direction of the first mat-vec: x0 = dUdt (warm start, cgmres.hpp:99)
     T ax0[MAXM];
     C.template preamble<true>(bb, ax0, du);  // Fh in LDS (or HBM); b and A*dUdt in registers
+    if constexpr (NWT != 0) C.store_base();
     CGM_STAMP(C, 1);
     C.gmres(du, bb, ax0);
     CGM_STAMP(C, 12);

@@ -31,12 +31,28 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_zero_fill(float x) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xf, true));
 }
+// The same for a control that writes EVERY lane (row mask 0xf: the in-row shifts): the move needs no previous value of
+// its destination, so none is materialised (update_dpp's `old` operand costs a v_mov_b32 per half).
+template <int CTRL>
+__device__ __forceinline__ double dpp_row_zero_fill(double x) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_zero_fill(float x) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xf, 0xf, true));
+}
 // the partner's value in step STEP (0..5) of the scan, 0 where the lane has none
-template <int STEP, class T>
+// REV (in-row steps only): the partner is the lane ABOVE — a scan from the highest lane of a 16-lane row downwards
+template <int STEP, bool REV = false, class T>
 __device__ __forceinline__ T scan_partner(T x) {
   static_assert(STEP >= 0 && STEP < 6, "six steps cover 64 lanes");
-  if constexpr (STEP < 4)
-    return dpp_zero_fill<0x110 + (1 << STEP), 0xf>(x);  // row_shr:1,2,4,8
+  static_assert(!REV || STEP < 4, "reverse scans stay inside a row");
+  if constexpr (REV)
+    return dpp_row_zero_fill<0x100 + (1 << STEP)>(x);  // row_shl:1,2,4,8
+  else if constexpr (STEP < 4)
+    return dpp_row_zero_fill<0x110 + (1 << STEP)>(x);  // row_shr:1,2,4,8
   else if constexpr (STEP == 4)
     return dpp_zero_fill<DPP_ROW_BCAST15, 0xA>(x);
   else
@@ -145,17 +161,17 @@ template <class T>
 struct Aff2Levels {
   T d[6][4];
 };
-template <int STEP, class T>
+template <int STEP, bool REV = false, class T>
 __device__ __forceinline__ void aff2_step_vec(T* c, const T* D) {
-  const T p0 = scan_partner<STEP>(c[0]), p1 = scan_partner<STEP>(c[1]);
+  const T p0 = scan_partner<STEP, REV>(c[0]), p1 = scan_partner<STEP, REV>(c[1]);
   const T n0 = fma_t(D[1], p1, fma_t(D[0], p0, c[0] + p0));
   const T n1 = fma_t(D[3], p1, fma_t(D[2], p0, c[1] + p1));
   c[0] = n0, c[1] = n1;
 }
-template <int STEP, class T>
+template <int STEP, bool REV = false, class T>
 __device__ __forceinline__ void aff2_step_mat(T* D) {
-  const T q0 = scan_partner<STEP>(D[0]), q1 = scan_partner<STEP>(D[1]), q2 = scan_partner<STEP>(D[2]),
-          q3 = scan_partner<STEP>(D[3]);
+  const T q0 = scan_partner<STEP, REV>(D[0]), q1 = scan_partner<STEP, REV>(D[1]), q2 = scan_partner<STEP, REV>(D[2]),
+          q3 = scan_partner<STEP, REV>(D[3]);
   const T n0 = fma_t(D[1], q2, fma_t(D[0], q0, D[0] + q0));
   const T n1 = fma_t(D[1], q3, fma_t(D[0], q1, D[1] + q1));
   const T n2 = fma_t(D[3], q2, fma_t(D[2], q0, D[2] + q2));

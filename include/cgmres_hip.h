@@ -74,8 +74,10 @@ enum {
   CGMRES_HIP_FLAG_NO_WAVE = 16,        /* library's choice of mapping: never the wave mapping (small batches stay on wg) */
   CGMRES_HIP_FLAG_WAVE_FRESH_TRIG = 32, /* wave mapping: every Newton iteration evaluates sin/cos afresh (the path taken when a
                                           trajectory strays from the base trajectory by more than the rotation range) */
-  CGMRES_HIP_FLAG_WAVE_SERIAL_SWEEPS = 64 /* wave mapping: every mat-vec takes the serial state sweep (the fall-back of a Newton
+  CGMRES_HIP_FLAG_WAVE_SERIAL_SWEEPS = 64, /* wave mapping: every mat-vec takes the serial state sweep (the fall-back of a Newton
                                           iteration that does not settle) */
+  CGMRES_HIP_FLAG_ROW_NEWTON = 128     /* wg mapping, pendulum fp64, dim_u*dv <= 160: the state sweeps of the Arnoldi loop as
+                                          row-parallel Newton iterations on all four waves (tick_wg.hip.h: NWT) */
 };
 
 /* cgmres_hip_closed_loop_device advances up to this many consecutive ticks per kernel launch (the controller

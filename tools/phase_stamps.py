@@ -39,7 +39,7 @@ B, DV, KM = opt("batch", 4096), opt("dv", 50), opt("kmax", 10)
 NAME = "pendulum" if MODEL == "pendulum32" else MODEL
 DT = "f32" if MODEL == "pendulum32" else "f64"
 x0, u0, p = scenarios.batch(NAME, B)
-c = cg.CgmresBatch(NAME, batch=B, dv=DV, k_max=KM, tol=0.0, dtype=DT, variant=opt("variant", 0))
+c = cg.CgmresBatch(NAME, batch=B, dv=DV, k_max=KM, tol=0.0, dtype=DT, variant=opt("variant", 0), flags=opt("flags", 0))
 print("variant", c.variant, c.variant_name, "B", B, "dv", DV, "kmax", KM, DT)
 x0, u0 = x0.astype(c.np_dtype), u0.astype(c.np_dtype)
 c.set_ptau_repeat(p); c.init_u0(u0); c.init_u0_newton(u0, x0, p, 10)
@@ -55,6 +55,7 @@ names = {14: "loop top: before barrier_or", 15: "barrier_or (drains V row store)
          5: "sweep phase 2 (coeffs)", 18: "costate A: prologue (terminal costate, first fetches)", 19: "costate A: stage loop", 20: "costate A: tail stages",
          16: "costate A: four chunks side by side (record store when 18-20 are stamped)", 17: "costate: barrier",
          6: "sweep phase 3 (costate; B: boundaries + combine if chunk-parallel)", 7: "MGS rounds", 8: "norm+normalise+store",
+         21: "row Newton: x0/x2 scans", 22: "row Newton: iterations (visits = iterations)", 23: "row Newton: costate scans + out", 24: "row Newton: operands + stage coefficients",
          9: "Hessenberg scalar", 10: "loop exit barrier", 11: "back-subst", 12: "x update (V*y)", 13: "epilogue"}
 if c.variant == 4:  # the wave mapping's own stamp ids (tick_wave.hip.h)
     names = {11: "tick top / epilogue tail", 0: "x+hf, control rows", 1: "serial state sweeps (3 quads)", 2: "preamble: 3 x costate scans",
