@@ -20,7 +20,7 @@ MODEL_IDS = {"pendulum": PENDULUM, "arm_type_inverted_pendulum": PENDULUM, "msd"
 F64, F32 = 0, 1
 EXIT_NATURAL, EXIT_CONVERGED, EXIT_SMALL_RESIDUAL, EXIT_BREAKDOWN, EXIT_NONFINITE = 0, 1, 2, 3, 4
 FLAG_SERIAL_COSTATE, FLAG_IPW8, FLAG_NO_BINNING, FLAG_TWO_PASS_COSTATE = 1, 2, 4, 8
-FLAG_NO_WAVE, FLAG_WAVE_FRESH_TRIG, FLAG_WAVE_SERIAL_SWEEPS, FLAG_ROW_NEWTON = 16, 32, 64, 128
+FLAG_NO_WAVE, FLAG_WAVE_FRESH_TRIG, FLAG_WAVE_SERIAL_SWEEPS, FLAG_SERIAL_STATE_SWEEP = 16, 32, 64, 128
 ABI_VERSION = 2
 TICKS_PER_LAUNCH = 10  # CGMRES_HIP_TICKS_PER_LAUNCH: closed_loop_device fuses this many ticks per launch (wg mapping)
 

@@ -328,7 +328,7 @@ int cgmres_hip_create(const cgmres_hip_config* cfg, cgmres_hip_handle* out) {
   if (cfg->variant < 0 || cfg->variant > 4) return fail(CGMRES_HIP_EINVAL, "unknown variant %d", cfg->variant);
   if (cfg->flags & ~(CGMRES_HIP_FLAG_SERIAL_COSTATE | CGMRES_HIP_FLAG_IPW8 | CGMRES_HIP_FLAG_NO_BINNING | CGMRES_HIP_FLAG_TWO_PASS_COSTATE |
                      CGMRES_HIP_FLAG_NO_WAVE | CGMRES_HIP_FLAG_WAVE_FRESH_TRIG | CGMRES_HIP_FLAG_WAVE_SERIAL_SWEEPS |
-                     CGMRES_HIP_FLAG_ROW_NEWTON))
+                     CGMRES_HIP_FLAG_SERIAL_STATE_SWEEP))
     return fail(CGMRES_HIP_EINVAL, "unknown flags 0x%x", cfg->flags);
   if (cfg->reserved != 0) return fail(CGMRES_HIP_EINVAL, "cgmres_hip_config.reserved must be 0 (got %d)", cfg->reserved);
   if (int rc = check_device(cfg->device)) return rc;

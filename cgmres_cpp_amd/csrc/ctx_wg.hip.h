@@ -213,7 +213,7 @@ struct CtxWg final : cgmres_hip_ctx {
     // row-parallel Newton state sweeps (WgCtx::NWT): the full plan's 16-instance kernel with the parallel costate sweep
     if constexpr (M::HAS_QUAD_SWEEP && std::is_same<T, double>::value) {
       const size_t extra = size_t(cfg.dv) * NWT_TABX * sizeof(T);
-      if ((cfg.flags & CGMRES_HIP_FLAG_ROW_NEWTON) && !wave && par == 1 && want == 16 && !big && !lean && !fh_hbm &&
+      if (!(cfg.flags & CGMRES_HIP_FLAG_SERIAL_STATE_SWEEP) && !wave && par == 1 && want == 16 && !big && !lean && !fh_hbm &&
           cfg.dv <= 63 && cfg.k_max <= 12 && lds_bytes + extra <= kLdsLimit &&
           // (the base trajectory of the Newton sweeps lives in the stage table and the costate-scan scratch during the loop)
           WgLds<M, T, 16, NWT_TABX>::tab_count(cfg.dv) >= WgCtx<M, T, 16, 10, false, 1, 1>::base_tab_scalars() &&

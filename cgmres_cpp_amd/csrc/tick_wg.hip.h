@@ -1484,13 +1484,7 @@ struct WgCtx {
   template <class After, class Idle>
   __device__ __forceinline__ void ax(bool only_active, After&& after_sweep, Idle&& idle_work) {
     CGM_STAMP(*this, 3);
-    if constexpr (NWT != 0) {
-      if (tid >= 64) idle_work();
-      row_newton_sweep<F_AX>(dtau_h, S.W, only_active);
-      CGM_STAMP(*this, 4);
-    } else {
-      f_eval<true, F_AX>(S.xh, dtau_h, S.W, only_active, after_sweep, idle_work);
-    }
+    f_eval<true, F_AX>(S.xh, dtau_h, S.W, only_active, after_sweep, idle_work);
     __syncthreads();
     CGM_STAMP(*this, 6);
   }
@@ -1593,7 +1587,7 @@ struct WgCtx {
   // Stages outside the horizon (s >= dv; the last lanes of the row) are IDENTITY maps by construction — their step
   // sizes and coefficients are zeroed once per sweep — so the folds and expansions below carry no per-stage selects.
   template <int MODE>
-  __device__ __forceinline__ void row_newton_sweep(T dtau, T* out, bool only_active) {
+  __device__ __forceinline__ void row_newton_sweep(T dtau, T* out, bool run) {
     constexpr int NU = M::NU, NP = M::NP, NBW = M::NBW;
     static_assert(MODE == F_AX, "only the mat-vec of the Arnoldi loop");
     static_assert(NU == 3 && NP == 2 && M::NUL == 1, "written for the pendulum's stage");
@@ -1604,7 +1598,6 @@ struct WgCtx {
     asm volatile("" : "+v"(tid_o));
     const int r = tid_o & 15, inst = tid_o >> 4;
     const int dv = P.dv, s_0 = SPL * r;
-    const bool run = valid && (!only_active || S.flag[inst] != 0);
     const T* Wr = S.W + inst * P.Lp;
     const T* Ur = S.U + inst * P.Lp;
     const T ee = -dtau * M::C22;
@@ -1677,8 +1670,7 @@ struct WgCtx {
 #pragma unroll
     for (int q = 0; q < SPL; ++q) ad[q] = dx0[q], a1[q] = T(0);
     const T rmax = T(0.9) * sqrt_t<T>(T(decltype(mc)::rot_zmax));
-    const int n_it = (P.wave_dbg & 2) ? 0 : NEWTON_MAX;
-    for (int it = 0; it < n_it; ++it) {
+    for (int it = 0; it < NEWTON_MAX; ++it) {
       T jq[SPL], c0q[SPL], c1q[SPL];
       T amax = T(0);  // (stages outside the horizon carry harmless finite values)
 #pragma unroll
@@ -1974,10 +1966,17 @@ struct WgCtx {
     // path — 16 lanes of wave 1 (one per instance) do column k-1 while wave 0 runs the first chunk of sweep k, where
     // the coefficient waves would otherwise wait; the last column is done in place.  With tol > 0 the column decides
     // whether the next mat-vec runs at all (gmres.hpp:93-95) and stays where the reference has it.
-    const bool defer_hess = IPW * 16 >= 128 && P.tol == T(0);  // workgroup-uniform
+    // (NWT: the rows of a workgroup do not meet inside the loop at all — every row does its own column in place)
+    const bool defer_hess = NWT == 0 && IPW * 16 >= 128 && P.tol == T(0);  // workgroup-uniform
     int k = 0;
     for (; k < kmax; ++k) {  // gmres.hpp:46
       CGM_STAMP(*this, 14);
+      if constexpr (NWT != 0) {
+        // Row-parallel sweeps: everything an iteration touches in LDS — the row of W, the row's small Krylov arrays —
+        // is written and read by the 16 lanes of ONE row, i.e. inside one wave, whose LDS operations complete in
+        // order: no workgroup barrier in the loop, and every wave leaves it when ITS four rows are done.
+        if (!__any(active)) break;
+      } else {
       // Workgroup barrier that orders LDS only (W and the flags are what the sweep lanes need).  __syncthreads()
       // would also drain this wave's HBM store of the new basis row (s_waitcnt vmcnt(0)) — nobody else reads it.
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -1998,6 +1997,7 @@ struct WgCtx {
 #pragma unroll
         for (int j = 0; j < IPW / 4; ++j) any |= (fl[j].x | fl[j].y) | (fl[j].z | fl[j].w);
         if (!any) break;
+      }
       }
       CGM_STAMP(*this, 15);
       // The first basis vectors this iteration needs are requested from HBM/L2 early.  Waves 1-3 do it NOW (the rows
@@ -2025,7 +2025,13 @@ struct WgCtx {
           hess_column(Hj, S.g + j * 3 * kmax, S.rho + j * k1, k - 1, S.hsub[j], true);
         }
       };
-      ax(true, request_rows, deferred_column);  // :48  W <- A v_k, in place
+      if constexpr (NWT != 0) {
+        CGM_STAMP(*this, 3);
+        row_newton_sweep<F_AX>(dtau_h, S.W, active);  // :48  W <- A v_k, in place
+        CGM_STAMP(*this, 6);
+      } else {
+        ax(true, request_rows, deferred_column);  // :48  W <- A v_k, in place
+      }
       if (active) {
         lds_to_reg(w, S.W);
         if constexpr (NWT != 0) {

@@ -76,8 +76,9 @@ enum {
                                           trajectory strays from the base trajectory by more than the rotation range) */
   CGMRES_HIP_FLAG_WAVE_SERIAL_SWEEPS = 64, /* wave mapping: every mat-vec takes the serial state sweep (the fall-back of a Newton
                                           iteration that does not settle) */
-  CGMRES_HIP_FLAG_ROW_NEWTON = 128     /* wg mapping, pendulum fp64, dim_u*dv <= 160: the state sweeps of the Arnoldi loop as
-                                          row-parallel Newton iterations on all four waves (tick_wg.hip.h: NWT) */
+  CGMRES_HIP_FLAG_SERIAL_STATE_SWEEP = 128 /* wg mapping, pendulum fp64: keep the serial state sweep on one wave in the Arnoldi
+                                          loop instead of the row-parallel Newton sweeps (tick_wg.hip.h: NWT), which the
+                                          library takes where they apply (full LDS plan, 42 <= dv <= 63, k_max <= 12) */
 };
 
 /* cgmres_hip_closed_loop_device advances up to this many consecutive ticks per kernel launch (the controller

@@ -306,7 +306,7 @@ PAR_CASES = [
 ]
 # how the parallel form is asked for -> (variant, flags, the name the handle must resolve to; None = whatever fits)
 PAR_FORMS = {
-    "lds-scratch": (2, 0, None),
+    "lds-scratch": (2, "SERIAL_STATE", None),  # (with the serial state sweep: the row-Newton kernel has no costate sweep of its own in the loop)
     "two-pass": (2, "TWO_PASS", "wg+two-pass-costate"),
     "lean-two-pass": (3, 0, "wg-lean+two-pass-costate"),
 }
@@ -321,7 +321,7 @@ def test_chunk_parallel_costate_vs_serial_and_oracle(orc, model, dv, kmax, tol, 
     the serial kernel instantiation of the same plan) at horizon lengths around the chunking's edge cases.
     Teacher-forced ticks, early exits included (tol > 0)."""
     variant, flags, want_name = PAR_FORMS[form]
-    flags = cg.FLAG_TWO_PASS_COSTATE if flags == "TWO_PASS" else flags
+    flags = {"TWO_PASS": cg.FLAG_TWO_PASS_COSTATE, "SERIAL_STATE": cg.FLAG_SERIAL_STATE_SWEEP}.get(flags, flags)
     f32 = dtype == "f32"
     x0, u0, p = orc.batch_scenario(model, B)
     try:
@@ -405,7 +405,10 @@ def test_chunk_parallel_costate_form_follows_the_lds_budget():
     """Which costate sweep a handle gets: the LDS-scratch form where its 23.5 KB fit (headline), the two-pass form with
     4 chunks where only boundary records fit (dim_u*dv = 159, k = 12; long vectors; the lean plans of the pendulum),
     the serial sweep on request or when not even those fit."""
-    for kw, want in ((dict(model=0, dv=50, k_max=10, variant=2), "wg+parallel-costate"),
+    for kw, want in ((dict(model=0, dv=50, k_max=10, variant=2), "wg+row-newton"),
+                     (dict(model=0, dv=50, k_max=10, variant=2, flags=cg.FLAG_SERIAL_STATE_SWEEP), "wg+parallel-costate"),
+                     (dict(model=0, dv=40, k_max=10, variant=2), "wg+parallel-costate"),  # (row-Newton: 42 <= dv <= 63)
+                     (dict(model=0, dv=50, k_max=10, variant=2, dtype="f32"), "wg+parallel-costate"),
                      (dict(model=0, dv=53, k_max=12, variant=2), "wg+two-pass-costate"),
                      (dict(model=1, dv=50, k_max=10, variant=2), "wg+two-pass-costate"),
                      (dict(model=0, dv=50, k_max=10, variant=3), "wg-lean+two-pass-costate"),
