@@ -1968,6 +1968,10 @@ struct WgCtx {
     // whether the next mat-vec runs at all (gmres.hpp:93-95) and stays where the reference has it.
     // (NWT: the rows of a workgroup do not meet inside the loop at all — every row does its own column in place)
     const bool defer_hess = NWT == 0 && IPW * 16 >= 128 && P.tol == T(0);  // workgroup-uniform
+    // NWT in fixed-k mode: no column is needed before the triangular solve either, and no wave has idle time to hide one
+    // in — the loop only records h(k+1,k) (in the slot of the reflector's second word, which is what it becomes) and
+    // the QR factorisation of the whole Hessenberg matrix follows the loop, the columns spread over the lanes of the row.
+    const bool lazy_qr = NWT != 0 && P.tol == T(0);
     int k = 0;
     for (; k < kmax; ++k) {  // gmres.hpp:46
       CGM_STAMP(*this, 14);
@@ -2147,7 +2151,8 @@ struct WgCtx {
           // decision is therefore row-uniform.
           CGM_STAMP(*this, 8);
           // (deferred in fixed-k mode, except for the last column: no sweep follows it)
-          const bool column_now = !defer_hess || k + 1 == kmax;
+          const bool column_now = !lazy_qr && (!defer_hess || k + 1 == kmax);
+          if (lazy_qr && r == 0) gi[3 * k + 1] = hn;
           const T en = column_now ? hess_column(Hi, gi, rhoi, k, hn, r == 0) : T(1);
           CGM_STAMP(*this, 9);
           if (column_now && abs_t(en) < P.tol) {  // :93-95 — converged: column k is NOT used by the solve
@@ -2161,7 +2166,46 @@ struct WgCtx {
         }
       }
     }
-    __syncthreads();
+    if constexpr (NWT == 0) __syncthreads();  // (NWT: the status words of a row are its own wave's)
+    if constexpr (NWT != 0) {
+      if (lazy_qr) {
+        // gmres.hpp:71-90 for all columns at once: lane c of the row owns column c and carries its running entry `a`
+        // through the reflectors in order — step i: lane i turns (a, h(i+1,i)) into reflector i (the same expressions as
+        // hess_column) and leaves it in LDS, every lane reads it back (same wave: LDS operations complete in order),
+        // the lanes c > i apply it to their column, and all lanes advance the residual vector.  Per column the
+        // arithmetic and its order are those of hess_column; the serial chain is k_max steps instead of k_max^2 / 2.
+        const int rs = S.reason[inst], nx = S.nax[inst];
+        const int n_col = !valid ? 0 : (rs == 0 ? nx : nx - 1);  // (a breakdown leaves its own column unrotated, :63-65)
+        const int c = r < kmax ? r : 0;
+        T* Hc = Hi + hoff(c);
+        const bool mine = r < n_col;
+        T a = mine ? Hc[0] : T(0);
+        T ek = rhoi[0];
+        for (int i = 0; i < kmax; ++i) {
+          if (!__any(i < n_col)) break;
+          const bool on = i < n_col;
+          const T cN = gi[3 * i + 1];
+          const T sigma = -(a < T(0.0) ? T(-1.0) : T(1.0)) * sqrt_t<T>(a * a + cN * cN);
+          const T q0 = a - sigma;
+          const T q2 = T(2.0) / (q0 * q0 + cN * cN);
+          if (on && r == i) {
+            gi[3 * i] = q0, gi[3 * i + 2] = q2;
+            Hc[i] = sigma;
+          }
+          const T g0 = gi[3 * i], g1 = cN, g2 = gi[3 * i + 2];
+          const T beta_r = g0 * ek * g2;
+          if (on && r == 0) rhoi[i] = ek - beta_r * g0;
+          ek = on ? -beta_r * g1 : ek;
+          if (mine && r > i) {
+            const T cn = Hc[i + 1];
+            const T beta = (g0 * a + g1 * cn) * g2;
+            Hc[i] = a - beta * g0;
+            a = cn - beta * g1;
+          }
+        }
+        if (r == 0 && n_col > 0) rhoi[n_col] = ek;
+      }
+    }
     CGM_STAMP(*this, 10);
     // natural exit: every column is used
     const int reason = S.reason[inst];
@@ -2217,7 +2261,7 @@ struct WgCtx {
       }
     }
     if constexpr (PARK) load_vec(xv, park_row);
-    __syncthreads();
+    if constexpr (NWT == 0) __syncthreads();  // (NWT: y is written and read by the lanes of one row, i.e. one wave)
     CGM_STAMP(*this, 11);
     if (valid && reason <= 1) {
       // x += V[:,0:ks] y  (gmres.hpp:110-111), accumulated j-ascending from 0 like matrix.hpp:82-91
