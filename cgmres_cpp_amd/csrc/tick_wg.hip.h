@@ -1429,10 +1429,6 @@ struct WgCtx {
       __threadfence_block();
       __syncthreads();  // drains vmcnt: the HBM tables are complete and visible to the other waves of this CU
       CGM_STAMP(*this, 4);
-      if constexpr (NWT != 0) {
-        capture_base();
-        __syncthreads();  // the table has been read before the coefficients overwrite it
-      }
       sweep_coeffs<false, F_PLAIN>(dtau_h, S.R, S.Fh, false);  // (S.Fh is S.W itself when fh_hbm)
       __syncthreads();
       CGM_STAMP(*this, 5);
@@ -1517,27 +1513,6 @@ struct WgCtx {
   struct NoBase {};
   std::conditional_t<ROW_NEWTON, RowBase, NoBase> nb;
   mutable bool row_moved = true;  // the published direction changed at least one control of this row (publish_direction)
-  // call after the preamble's sweep #1 has left x / trig in S.R and x(dv) in S.xT, before its coefficients overwrite them
-  __device__ __forceinline__ void capture_base() {
-    const int dv = P.dv;
-    T x1n[SPL + 1];
-#pragma unroll
-    for (int q = 0; q <= SPL; ++q) {
-      const int s = SPL * r + q;
-      T v = S.R[tab_off(s < dv ? s : 0, 1) + inst];
-      if (s == dv) v = S.xT[1 * IPW + inst];
-      x1n[q] = s <= dv ? v : T(0);
-    }
-#pragma unroll
-    for (int q = 0; q < SPL; ++q) {
-      const int s = SPL * r + q, sc = s < dv ? s : 0;
-      T x0 = S.R[tab_off(sc, M::QSLOT_XA) + inst], x2 = S.R[tab_off(sc, M::QSLOT_XB) + inst];
-      if (s == dv) x0 = S.xT[0 * IPW + inst], x2 = S.xT[2 * IPW + inst];
-      if (s > dv) x0 = T(0), x2 = T(0);
-      nb.x0[q] = x0, nb.x1[q] = x1n[q], nb.x2[q] = x2;
-      mc.sincos_pair(x0 - x1n[q], x1n[q], &nb.sd[q], &nb.cd[q], &nb.s1[q], &nb.c1[q]);
-    }
-  }
   // During the Arnoldi loop the base lives in LDS — in the stage table and the costate-scan scratch, which only the
   // preamble uses (ctx_wg checks that they are large enough) — as pairs [array][q / 2][thread]: every lane reads back
   // exactly what it wrote (no barrier), 16 bytes per access, conflict-free.  Call after the preamble's last barrier.
@@ -1580,17 +1555,214 @@ struct WgCtx {
     *sn_out = sb + fma_t(sb, cm1, cb * sn);
     *cs_out = cb + fma_t(cb, cm1, -(sb * sn));
   }
+  // Costate recurrence (cgmres.hpp:145-153) and dH/du (:156-161) of the row's instance from the states x(s) and trig
+  // values of the owned stages (x of "stage dv" = the terminal state), in registers:
+  //   MODE F_PLAIN: out = F        F_RHS: out = (F*(1-zeta h) - Fh)/h  (:91-96)        F_AX: out = (F - Fh)/h  (:173-174)
+  // PendulumDev::costate_step is affine in the costate with (l1, l3) closed in themselves, l0 a running sum over l3 and
+  // l2 a geometric recurrence over l0 / l3 — three scans DOWN the row (partner = the lane above), each as local fold,
+  // in-row scan, local expansion.  The terminal costate (cgmres.hpp:143) is the starting value of the lane that holds
+  // stage dv (nothing above it but identities).  urow: the row of controls the stages were run with (U, or W = U + h d;
+  // may be `out`'s row: every control is read before the first result is stored).
+  template <int MODE>
+  __device__ __forceinline__ void row_costate(const T* x0f, const T* y1, const T* x2f, const T* y3, const T* sd, const T* cd,
+                                              const T* c1, const T* urow, T dtau, T* out, bool run, int tid_o) {
+    constexpr int NU = M::NU, NP = M::NP, NBW = M::NBW;
+    static_assert(NU == 3 && NP == 2 && M::NUL == 1, "written for the pendulum's stage");
+    const int r = tid_o & 15, inst = tid_o >> 4;
+    const int dv = P.dv, s_0 = SPL * r;
+    const T ee = -dtau * M::C22, a = T(1) - dtau * M::As;
+    const T sc_phi = MODE == F_RHS ? P.one_m_zh : T(1.0);
+    const T sc = MODE == F_PLAIN ? T(1.0) : (MODE == F_RHS ? P.one_m_zh * P.inv_h : P.inv_h);
+    bool tr[SPL];
+    T dq[SPL], eq[SPL];
+#pragma unroll
+    for (int q = 0; q < SPL; ++q) {
+      tr[q] = s_0 + q < dv;
+      dq[q] = tr[q] ? dtau : T(0), eq[q] = tr[q] ? ee : T(0);
+    }
+    const int q_term = dv - s_0;
+    const bool has_term = q_term >= 0 && q_term < SPL;
+    T bw[SPL][NBW], phi0[SPL];
+    T lT[M::NX] = {T(0), T(0), T(0), T(0)};
+    {
+      T u0[SPL], u1[SPL], u2[SPL], pp[SPL][NP], fh[SPL][NU];
+#pragma unroll
+      for (int q = 0; q < SPL; ++q) {  // every LDS operand first (addresses clamped into the horizon: no branch, one wait)
+        const int s = s_0 + q, sk = s < dv ? s : dv - 1, sp = s < dv ? s : dv;
+        u0[q] = urow[sk * NU], u1[q] = urow[sk * NU + 1], u2[q] = urow[sk * NU + 2];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) pp[q][j] = get_p(inst, sp * NP + j);
+#pragma unroll
+        for (int j = 0; j < NU; ++j) fh[q][j] = MODE == F_PLAIN ? T(0) : S.Fh[inst * P.Lp + sk * NU + j];
+      }
+#pragma unroll
+      for (int q = 0; q < SPL; ++q) {
+        const int s = s_0 + q;
+        const T x[M::NX] = {x0f[q], y1[q], x2f[q], y3[q]};
+        const T tg[3] = {sd[q], cd[q], c1[q]}, u[NU] = {u0[q], u1[q], u2[q]};
+        T phi[NU], bq[NBW];
+        M::stage_coeffs(bq, phi, x, u, pp[q], tg, dtau);
+#pragma unroll
+        for (int cc = 0; cc < NBW; ++cc) bw[q][cc] = tr[q] ? bq[cc] : T(0);
+        phi0[q] = MODE == F_PLAIN ? phi[0] : (phi[0] * sc_phi - fh[q][0]) * P.inv_h;
+        if (run && tr[q]) {
+          out[inst * P.Lp + s * NU + 1] = MODE == F_PLAIN ? phi[1] : (phi[1] * sc_phi - fh[q][1]) * P.inv_h;
+          out[inst * P.Lp + s * NU + 2] = MODE == F_PLAIN ? phi[2] : (phi[2] * sc_phi - fh[q][2]) * P.inv_h;
+        }
+        if (q == q_term) M::dPhidx(lT, x, pp[q]);
+      }
+    }
+    CGM_STAMP(*this, 24);
+    T L0[SPL], L2[SPL], L3[SPL];  // costate components ENTERING the owned stages (lambda of stage s + 1)
+    {
+      // (l1, l3): n1 = l1 + bw1 l3 + bw5,  n3 = l3 + dq l1 + eq l3; the lane with stage dv starts from the constant map
+      T D[4] = {has_term ? T(-1) : T(0), T(0), T(0), has_term ? T(-1) : T(0)};
+      T c[2] = {has_term ? lT[1] : T(0), has_term ? lT[3] : T(0)};
+#pragma unroll
+      for (int q = SPL - 1; q >= 0; --q) {
+        const T b1 = bw[q][1];
+        const T n00 = fma_t(b1, D[2], D[0]);
+        const T n01 = fma_t(b1, D[3], D[1] + b1);
+        const T n10 = fma_t(eq[q], D[2], fma_t(dq[q], D[0], D[2] + dq[q]));
+        const T n11 = fma_t(eq[q], D[3], fma_t(dq[q], D[1], D[3] + eq[q]));
+        const T m0 = fma_t(b1, c[1], c[0] + bw[q][5]);
+        const T m1 = fma_t(eq[q], c[1], fma_t(dq[q], c[0], c[1]));
+        D[0] = n00, D[1] = n01, D[2] = n10, D[3] = n11, c[0] = m0, c[1] = m1;
+      }
+      aff2_step_vec<0, true>(c, D), aff2_step_mat<0, true>(D);
+      aff2_step_vec<1, true>(c, D), aff2_step_mat<1, true>(D);
+      aff2_step_vec<2, true>(c, D), aff2_step_mat<2, true>(D);
+      aff2_step_vec<3, true>(c, D);
+      // costate entering the lane's last stage (the lanes above the one with stage dv deliver zeros)
+      T l1 = scan_partner<0, true>(c[0]), l3 = scan_partner<0, true>(c[1]);
+      l1 = has_term ? lT[1] : l1, l3 = has_term ? lT[3] : l3;
+      T l0s = has_term ? lT[0] : T(0);  // l0 relative to the lane's entry: n0 = l0 + (bw4 + bw0 l3)
+#pragma unroll
+      for (int q = SPL - 1; q >= 0; --q) {
+        L3[q] = l3, L0[q] = l0s;
+        l0s += fma_t(bw[q][0], l3, bw[q][4]);
+        const T n1 = fma_t(bw[q][1], l3, l1 + bw[q][5]);
+        const T n3 = fma_t(eq[q], l3, fma_t(dq[q], l1, l3));
+        l1 = n1, l3 = n3;
+      }
+      T t0 = l0s;
+      t0 += scan_partner<0, true>(t0);
+      t0 += scan_partner<1, true>(t0);
+      t0 += scan_partner<2, true>(t0);
+      t0 += scan_partner<3, true>(t0);
+      const T in0 = scan_partner<0, true>(t0);
+      // l2: n2 = aq l2 + (bw2 l3 + dq l0), aq = 1 - dq As
+      T e2 = has_term ? lT[2] : T(0);
+#pragma unroll
+      for (int q = SPL - 1; q >= 0; --q) {
+        L0[q] += in0;
+        e2 = fma_t(fma_t(-M::As, dq[q], T(1)), e2, fma_t(bw[q][2], L3[q], dq[q] * L0[q]));
+      }
+      {
+        const T a2 = a * a;
+        T m = a2 * a2;  // (a lane with fewer than four stages has nothing but zeros above it: its multiplier is not used)
+        e2 = fma_t(m, scan_partner<0, true>(e2), e2), m = m * m;
+        e2 = fma_t(m, scan_partner<1, true>(e2), e2), m = m * m;
+        e2 = fma_t(m, scan_partner<2, true>(e2), e2), m = m * m;
+        e2 = fma_t(m, scan_partner<3, true>(e2), e2);
+      }
+      T l2 = scan_partner<0, true>(e2);
+      l2 = has_term ? lT[2] : l2;
+#pragma unroll
+      for (int q = SPL - 1; q >= 0; --q) {
+        L2[q] = l2;
+        l2 = fma_t(fma_t(-M::As, dq[q], T(1)), l2, fma_t(bw[q][2], L3[q], dq[q] * L0[q]));
+      }
+    }
+    if (run) {
+#pragma unroll
+      for (int q = 0; q < SPL; ++q) {
+        if (tr[q]) {
+          const T dF = fma_t(bw[q][3], L3[q], L2[q] * M::Bs);  // B^T lambda, costate_step
+          out[inst * P.Lp + (s_0 + q) * NU] = fma_t(dF, sc, phi0[q]);
+        }
+      }
+    }
+    CGM_STAMP(*this, 23);
+  }
+
+  // The preamble of a tick (see preamble()) for the row-parallel kernel: the three state sweeps stay the serial quad
+  // sweeps, side by side on waves 0-2 (#1 leaves its stage table in LDS, #2 / #3 park theirs in HBM); everything behind
+  // them — stage coefficients, costate recurrence, dH/du — every row does for itself in registers (row_costate), one
+  // sweep after the other with no workgroup barrier in between: F(U,x+hf,t+h) -> S.Fh, A*dUdt and b through the row
+  // of W into registers.  The stage states of sweep #1, with freshly evaluated sin / cos, become the base of the
+  // Newton sweeps (nb; moved to LDS by store_base once every lane is done with the stage table).
+  __device__ __forceinline__ void preamble_rows(T* bb, T* ax0) {
+    make_xh();
+    __syncthreads();
+    const size_t tab_n = Lds::tab_count(P.dv);
+    T* tab0 = P.scr + size_t(blockIdx.x) * 2 * tab_n;
+    T* tab1 = tab0 + tab_n;
+    T* xT0 = S.xT, *xT1 = S.xT + M::NX * IPW, *xT2 = S.xT + 2 * M::NX * IPW;
+    sweep_state<false, false>(0, S.xh, dtau_h, S.R, xT0, false);
+    sweep_state<false, false>(64, S.xs, dtau_0, tab0, xT1, false);
+    sweep_state<true, false>(128, S.xh, dtau_h, tab1, xT2, false);
+    __threadfence_block();
+    __syncthreads();  // drains vmcnt: the HBM tables are complete and visible to the other waves of this CU
+    CGM_STAMP(*this, 4);
+    int tid_o = tid;
+    asm volatile("" : "+v"(tid_o));
+    const int r = tid_o & 15, inst = tid_o >> 4, dv = P.dv;
+    struct Stages {
+      T x0[SPL], x1[SPL], x2[SPL], x3[SPL], sd[SPL], cd[SPL], c1[SPL];
+    };
+    // x and trig of the owned stages from a stage table (slot map: PendulumDev::quad_stage), x(dv) from xT
+    auto read_stages = [&](Stages& g, const T* tab, const T* xT) {
+#pragma unroll
+      for (int q = 0; q < SPL; ++q) {
+        const int s = SPL * r + q, sk = s < dv ? s : 0;
+        const T* e = tab + tab_off(sk) + inst;
+        g.x0[q] = e[M::QSLOT_XA * IPW], g.x1[q] = e[1 * IPW], g.x2[q] = e[M::QSLOT_XB * IPW], g.x3[q] = T(0);
+        g.sd[q] = e[M::TRIG_SLOT0 * IPW], g.cd[q] = e[(M::TRIG_SLOT0 + 1) * IPW], g.c1[q] = e[(M::TRIG_SLOT0 + 2) * IPW];
+      }
+#pragma unroll
+      for (int q = 0; q < SPL; ++q) {
+        const int s = SPL * r + q;
+        if (s == dv) g.x0[q] = xT[0 * IPW + inst], g.x1[q] = xT[1 * IPW + inst], g.x2[q] = xT[2 * IPW + inst], g.x3[q] = xT[3 * IPW + inst];
+        if (s > dv) g.x0[q] = T(0), g.x1[q] = T(0), g.x2[q] = T(0);
+      }
+    };
+    const T* Urow = S.U + inst * P.Lp;
+    {
+      Stages g;
+      read_stages(g, S.R, xT0);
+#pragma unroll
+      for (int q = 0; q < SPL; ++q) {
+        nb.x0[q] = g.x0[q], nb.x1[q] = g.x1[q], nb.x2[q] = g.x2[q];
+        mc.sincos_pair(g.x0[q] - g.x1[q], g.x1[q], &nb.sd[q], &nb.cd[q], &nb.s1[q], &nb.c1[q]);
+      }
+      row_costate<F_PLAIN>(g.x0, g.x1, g.x2, g.x3, g.sd, g.cd, g.c1, Urow, dtau_h, S.Fh, valid, tid_o);
+    }
+    {
+      Stages g;
+      read_stages(g, tab1, xT2);
+      row_costate<F_AX>(g.x0, g.x1, g.x2, g.x3, g.sd, g.cd, g.c1, S.W + inst * P.Lp, dtau_h, S.W, valid, tid_o);
+      lds_to_reg(ax0, S.W);
+    }
+    {
+      Stages g;
+      read_stages(g, tab0, xT1);
+      row_costate<F_RHS>(g.x0, g.x1, g.x2, g.x3, g.sd, g.cd, g.c1, Urow, dtau_0, S.W, valid, tid_o);
+      lds_to_reg(bb, S.W);
+    }
+    __syncthreads();  // every lane is done with the stage table: the base may move in (store_base)
+  }
+
   // F(U + h d, x + h f, t + h) - F(U, x + h f, t + h), / h, for the row's instance (W holds U + h d on entry, the
   // result on exit): state recurrence, costate recurrence and dH/du all in the registers of the row's 16 lanes — no
   // stage table, no workgroup barrier; the only LDS traffic is the row's own operands (W, U, F(U,x+hf,t+h), ptau).
   // COLLECTIVE over the wave (wave-uniform branches on __any).
   // Stages outside the horizon (s >= dv; the last lanes of the row) are IDENTITY maps by construction — their step
   // sizes and coefficients are zeroed once per sweep — so the folds and expansions below carry no per-stage selects.
-  template <int MODE>
-  __device__ __forceinline__ void row_newton_sweep(T dtau, T* out, bool run) {
-    constexpr int NU = M::NU, NP = M::NP, NBW = M::NBW;
+  template <int MODE, class Mid>
+  __device__ __forceinline__ void row_newton_sweep(T dtau, T* out, bool run, Mid&& mid) {
+    constexpr int NU = M::NU;
     static_assert(MODE == F_AX, "only the mat-vec of the Arnoldi loop");
-    static_assert(NU == 3 && NP == 2 && M::NUL == 1, "written for the pendulum's stage");
     // (everything below derives from the thread index and is invariant over sweeps and ticks: left visible, the compiler
     // hoists it to the top of the kernel and keeps dozens of values alive across the Gram-Schmidt rounds — in scratch,
     // reloaded behind s_waitcnt vmcnt(0), i.e. behind the basis rows in flight)
@@ -1612,8 +1784,6 @@ struct WgCtx {
       u0[q] = Wr[e];
       du[q] = tr[q] ? u0[q] - Ur[e] : T(0);
     }
-    const int q_term = dv - s_0;                       // local index of "stage dv" (the terminal state), if in 0..SPL-1
-    const bool has_term = q_term >= 0 && q_term < SPL;
     // ---- x0, x2: difference to the base trajectory (zero initial difference)
     const T a = T(1) - dtau * M::As, bs = dtau * M::Bs;
     T dx0[SPL], dx2[SPL];
@@ -1738,113 +1908,8 @@ struct WgCtx {
         break;
       }
     }
-    // ---- costate (cgmres.hpp:145-153) and dH/du (:156-161) of the owned stages: the backward recurrence
-    //      PendulumDev::costate_step is affine in the costate with (l1, l3) closed in themselves, l0 a running sum over
-    //      l3 and l2 a geometric recurrence over l0 / l3 — three scans DOWN the row (partner = the lane above), each as
-    //      local fold, in-row scan, local expansion.  The terminal costate (cgmres.hpp:143) is the starting value of
-    //      the lane that holds stage dv (nothing above it but identities).
-    T bw[SPL][NBW], phi0[SPL];
-    T lT[M::NX] = {T(0), T(0), T(0), T(0)};
-    {
-      T u1[SPL], u2[SPL], pp[SPL][NP], fh[SPL][NU];
-#pragma unroll
-      for (int q = 0; q < SPL; ++q) {  // every LDS operand first (addresses clamped into the horizon: no branch, one wait)
-        const int s = s_0 + q, sc = s < dv ? s : dv - 1, sp = s < dv ? s : dv;
-        u1[q] = Wr[sc * NU + 1], u2[q] = Wr[sc * NU + 2];
-#pragma unroll
-        for (int j = 0; j < NP; ++j) pp[q][j] = get_p(inst, sp * NP + j);
-#pragma unroll
-        for (int j = 0; j < NU; ++j) fh[q][j] = S.Fh[inst * P.Lp + sc * NU + j];
-      }
-#pragma unroll
-      for (int q = 0; q < SPL; ++q) {
-        const int s = s_0 + q;
-        const T x[M::NX] = {x0f[q], y1[q], x2f[q], y3[q]};
-        const T tg[3] = {sd[q], cd[q], c1[q]}, u[NU] = {u0[q], u1[q], u2[q]};
-        T phi[NU], bq[NBW];
-        M::stage_coeffs(bq, phi, x, u, pp[q], tg, dtau);
-#pragma unroll
-        for (int cc = 0; cc < NBW; ++cc) bw[q][cc] = tr[q] ? bq[cc] : T(0);
-        phi0[q] = (phi[0] - fh[q][0]) * P.inv_h;
-        if (run && tr[q]) {
-          out[inst * P.Lp + s * NU + 1] = (phi[1] - fh[q][1]) * P.inv_h;
-          out[inst * P.Lp + s * NU + 2] = (phi[2] - fh[q][2]) * P.inv_h;
-        }
-        if (q == q_term) M::dPhidx(lT, x, pp[q]);
-      }
-    }
-    CGM_STAMP(*this, 24);
-    T L0[SPL], L2[SPL], L3[SPL];  // costate components ENTERING the owned stages (lambda of stage s + 1)
-    {
-      // (l1, l3): n1 = l1 + bw1 l3 + bw5,  n3 = l3 + dq l1 + eq l3; the lane with stage dv starts from the constant map
-      T D[4] = {has_term ? T(-1) : T(0), T(0), T(0), has_term ? T(-1) : T(0)};
-      T c[2] = {has_term ? lT[1] : T(0), has_term ? lT[3] : T(0)};
-#pragma unroll
-      for (int q = SPL - 1; q >= 0; --q) {
-        const T b1 = bw[q][1];
-        const T n00 = fma_t(b1, D[2], D[0]);
-        const T n01 = fma_t(b1, D[3], D[1] + b1);
-        const T n10 = fma_t(eq[q], D[2], fma_t(dq[q], D[0], D[2] + dq[q]));
-        const T n11 = fma_t(eq[q], D[3], fma_t(dq[q], D[1], D[3] + eq[q]));
-        const T m0 = fma_t(b1, c[1], c[0] + bw[q][5]);
-        const T m1 = fma_t(eq[q], c[1], fma_t(dq[q], c[0], c[1]));
-        D[0] = n00, D[1] = n01, D[2] = n10, D[3] = n11, c[0] = m0, c[1] = m1;
-      }
-      aff2_step_vec<0, true>(c, D), aff2_step_mat<0, true>(D);
-      aff2_step_vec<1, true>(c, D), aff2_step_mat<1, true>(D);
-      aff2_step_vec<2, true>(c, D), aff2_step_mat<2, true>(D);
-      aff2_step_vec<3, true>(c, D);
-      // costate entering the lane's last stage (the lanes above the one with stage dv deliver zeros)
-      T l1 = scan_partner<0, true>(c[0]), l3 = scan_partner<0, true>(c[1]);
-      l1 = has_term ? lT[1] : l1, l3 = has_term ? lT[3] : l3;
-      T l0s = has_term ? lT[0] : T(0);  // l0 relative to the lane's entry: n0 = l0 + (bw4 + bw0 l3)
-#pragma unroll
-      for (int q = SPL - 1; q >= 0; --q) {
-        L3[q] = l3, L0[q] = l0s;
-        l0s += fma_t(bw[q][0], l3, bw[q][4]);
-        const T n1 = fma_t(bw[q][1], l3, l1 + bw[q][5]);
-        const T n3 = fma_t(eq[q], l3, fma_t(dq[q], l1, l3));
-        l1 = n1, l3 = n3;
-      }
-      T t0 = l0s;
-      t0 += scan_partner<0, true>(t0);
-      t0 += scan_partner<1, true>(t0);
-      t0 += scan_partner<2, true>(t0);
-      t0 += scan_partner<3, true>(t0);
-      const T in0 = scan_partner<0, true>(t0);
-      // l2: n2 = aq l2 + (bw2 l3 + dq l0), aq = 1 - dq As
-      T e2 = has_term ? lT[2] : T(0);
-#pragma unroll
-      for (int q = SPL - 1; q >= 0; --q) {
-        L0[q] += in0;
-        e2 = fma_t(fma_t(-M::As, dq[q], T(1)), e2, fma_t(bw[q][2], L3[q], dq[q] * L0[q]));
-      }
-      {
-        const T a2 = a * a;
-        T m = a2 * a2;  // (a lane with fewer than four stages has nothing but zeros above it: its multiplier is not used)
-        e2 = fma_t(m, scan_partner<0, true>(e2), e2), m = m * m;
-        e2 = fma_t(m, scan_partner<1, true>(e2), e2), m = m * m;
-        e2 = fma_t(m, scan_partner<2, true>(e2), e2), m = m * m;
-        e2 = fma_t(m, scan_partner<3, true>(e2), e2);
-      }
-      T l2 = scan_partner<0, true>(e2);
-      l2 = has_term ? lT[2] : l2;
-#pragma unroll
-      for (int q = SPL - 1; q >= 0; --q) {
-        L2[q] = l2;
-        l2 = fma_t(fma_t(-M::As, dq[q], T(1)), l2, fma_t(bw[q][2], L3[q], dq[q] * L0[q]));
-      }
-    }
-    if (run) {
-#pragma unroll
-      for (int q = 0; q < SPL; ++q) {
-        if (tr[q]) {
-          const T dF = fma_t(bw[q][3], L3[q], L2[q] * M::Bs);  // B^T lambda, costate_step
-          out[inst * P.Lp + (s_0 + q) * NU] = fma_t(dF, P.inv_h, phi0[q]);
-        }
-      }
-    }
-    CGM_STAMP(*this, 23);
+    mid();
+    row_costate<MODE>(x0f, y1, x2f, y3, sd, cd, c1, Wr, dtau, out, run, tid_o);
   }
 
   // Hessenberg column k of one instance: stored reflectors, new reflector, residual rotation (gmres.hpp:71-90) — scalar
@@ -2021,7 +2086,7 @@ struct WgCtx {
             if (i + NKEEP < k) load_vec(vbuf[i], vrow(i + NKEEP));
         }
       };
-      if (NWT != 0 || tid >= 64) request_rows();  // (NWT: no serial sweep to keep clear of — every wave asks now)
+      if (NWT == 0 && tid >= 64) request_rows();
       auto deferred_column = [&]() {  // column k-1 of instance j = tid-64, if iteration k-1 produced one for it
         const int j = tid - 64;
         if (defer_hess && k > 0 && j >= 0 && j < IPW && S.reason[j] == 0 && S.nax[j] == k) {
@@ -2031,7 +2096,10 @@ struct WgCtx {
       };
       if constexpr (NWT != 0) {
         CGM_STAMP(*this, 3);
-        row_newton_sweep<F_AX>(dtau_h, S.W, active);  // :48  W <- A v_k, in place
+        // (the basis rows are requested between the Newton iterations and the costate scans: early enough to arrive
+        // behind the scans, late enough that their registers are not live across the iterations, where the register
+        // file is fullest — requested before the sweep they sit in AGPRs and every use in the rounds below is a copy)
+        row_newton_sweep<F_AX>(dtau_h, S.W, active, request_rows);  // :48  W <- A v_k, in place
         CGM_STAMP(*this, 6);
       } else {
         ax(true, request_rows, deferred_column);  // :48  W <- A v_k, in place
@@ -2370,8 +2438,12 @@ __global__ __launch_bounds__(IPW * 16) __attribute__((amdgpu_waves_per_eu(LEAN ?
     CGM_STAMP(C, 0);
     if constexpr (!LEAN) C.publish_direction(du);  // direction of the first mat-vec: x0 = dUdt (warm start, cgmres.hpp:99)
     T ax0[MAXM];
-    C.template preamble<true>(bb, ax0, du);  // Fh in LDS (or HBM); b and A*dUdt in registers
-    if constexpr (NWT != 0) C.store_base();
+    if constexpr (NWT != 0) {
+      C.preamble_rows(bb, ax0);
+      C.store_base();
+    } else {
+      C.template preamble<true>(bb, ax0, du);  // Fh in LDS (or HBM); b and A*dUdt in registers
+    }
     CGM_STAMP(C, 1);
     C.gmres(du, bb, ax0);
     CGM_STAMP(C, 12);

@@ -14,8 +14,12 @@ pytestmark = pytest.mark.gpu
 
 U_TOL = 1e-9
 DUDT_REL = 1e-7
-VARIANTS = [2, 1, 3, 4]  # 2 = "wg" (default mapping), 1 = "lane" (reference statement order), 3 = "wg-lean" (two workgroups per CU),
-#                          4 = "wave" (one wavefront per controller: the latency mapping; pendulum fp64, dv <= 63, k_max <= 10)
+# 2 = "wg" (default mapping; for the pendulum in fp64 at 42 <= dv <= 53 its row-parallel Newton sweeps, tick_wg.hip.h: NWT),
+# "2s" = the same with FLAG_SERIAL_STATE_SWEEP (the wg kernel with the serial quad sweep, where that differs),
+# 1 = "lane" (reference statement order), 3 = "wg-lean" (two workgroups per CU),
+# 4 = "wave" (one wavefront per controller: the latency mapping; pendulum fp64, dv <= 63, k_max <= 10)
+SERIAL_STATE = "2s"
+VARIANTS = [2, SERIAL_STATE, 1, 3, 4]
 
 
 def dudt_close(a, b, rel=DUDT_REL):
@@ -25,6 +29,11 @@ def dudt_close(a, b, rel=DUDT_REL):
 
 def new_batch(*a, **kw):
     """cg.CgmresBatch; a size / model the wave mapping does not serve skips the test case."""
+    if kw.get("variant") == SERIAL_STATE:
+        model = a[0] if a else kw.get("model")
+        if model not in (0, "pendulum") or kw.get("dtype", "f64") != "f64" or not 42 <= kw.get("dv", 0) <= 53:
+            pytest.skip("FLAG_SERIAL_STATE_SWEEP only changes the pendulum's fp64 kernel at 42 <= dv <= 53")
+        kw = dict(kw, variant=2, flags=kw.get("flags", 0) | cg.FLAG_SERIAL_STATE_SWEEP)
     try:
         return cg.CgmresBatch(*a, **kw)
     except cg.CgmresHipError as e:
