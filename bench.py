@@ -44,6 +44,7 @@ DIM_X, DIM_U, DIM_P = 4, 3, 2
 GLOBAL_BATCH = 4096
 # rocprofv3 PMC summary of this same command (tools/profile_bench.sh + tools/summarise_profile.py), newest first
 ISSUE_MODELS = [os.path.join(ROOT, "profiles", n) for n in ("r03_issue_model.json", "r02_issue_model.json")]
+INSTRUCTION_COUNTERS = os.path.join(ROOT, "profiles", "r04_wg_instruction_counters.json")
 KERNEL_OF_VARIANT = {1: "tick_lane_kernel", 2: "tick_wg_kernel", 3: "tick_wg_kernel", 4: "tick_wave_kernel"}
 
 
@@ -501,12 +502,24 @@ def main():
                 "kernel": f"{kernel_name} ({tpl} control step(s) of the batch per launch)", "launch_ms": launch_ms,
                 "ticks_per_launch": args.steps / n_launches, "algorithmic_bytes_per_launch": bytes_per_launch,
                 "rank": 0, "instances_per_launch": B}
-    for path in ISSUE_MODELS:
+    if "row-newton" in head["variant_name"]:
+        # the row-parallel kernel has no serial stage loop to model: what the SQ counters say it issues (own --pmc pass of
+        # this command, tools/profile_round4.sh), quoted only next to a timing of the same build
         try:
-            roofline["issue_slot_model"] = json.load(open(path))
-            break
-        except OSError:
+            ic = json.load(open(INSTRUCTION_COUNTERS))
+            if ic.get("library_sha256_16") == library_hash():
+                roofline["instruction_counters"] = {k: ic[k] for k in ("per_controller_and_tick", "cycles_per_tick",
+                                                                       "valu_issue_utilisation_per_simd", "note")}
+                roofline["instruction_counters"]["source"] = os.path.relpath(INSTRUCTION_COUNTERS, ROOT)
+        except (OSError, ValueError, KeyError):
             pass
+    else:
+        for path in ISSUE_MODELS:
+            try:
+                roofline["issue_slot_model"] = json.load(open(path))
+                break
+            except OSError:
+                pass
     out = {
         "metric": "C/GMRES control steps/sec, batch=4096 N=50 kmax=10; HBM GB/s vs roofline",
         "value": value, "unit": "control steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

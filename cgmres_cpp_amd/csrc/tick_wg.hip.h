@@ -1982,7 +1982,7 @@ struct WgCtx {
     // Gram-Schmidt rounds are bounded by the CU's 64 B/clk vector-memory path, not by issue.  The ring then serves the
     // rows from NKEEP on.  Pays for itself only where registers are left: the one-workgroup-per-CU kernels with short
     // vectors, with the solution vector parked in HBM for the duration of the loop like the long-vector kernels do.
-    constexpr int NKEEP = (!LEAN && MAXM <= 10 && NWT == 0) ? 2 : 0;  // (NWT: the Newton sweep needs the registers)
+    constexpr int NKEEP = (!LEAN && MAXM <= 10) ? 2 : 0;
     T vkeep[NKEEP > 0 ? NKEEP : 1][MAXM];
     // workgroup-uniform; longer bases use the plain streaming loop.  So does the lean plan: with 256 registers per wave the
     // twelve straight-line copies of the rounds push everything that lives across them (U, the sweep constants) into
