@@ -29,6 +29,11 @@
 //   * inside a chunk of stages the pendulum sweep advances its sin/cos values by rotation through the exact angle
 //     increment instead of re-evaluating them (PendulumDev::quad_stage_rot), with per-chunk fallbacks; in fixed-k mode
 //     (tol = 0) the Hessenberg column of an iteration is processed by an idle wave during the next sweep (gmres()).
+//   * template parameter NWT = 1 (pendulum fp64, full plan; the library's choice for the headline batch): inside the
+//     Arnoldi loop the three phases above give way to ROW-PARALLEL sweeps — every row of 16 lanes runs its instance's
+//     state recurrence as Newton's method on the whole trajectory (four stages per lane, in-row DPP scans) and the
+//     costate recurrence as three scans down the row, all in registers, with no workgroup barrier in the loop
+//     (row_newton_sweep / row_costate); the serial state sweep remains in the preamble only.
 // Statement order inside each instance follows cgmres.hpp:78-175 / gmres.hpp:28-112; what differs from the
 // reference is the association order of sums (16 partial sums + butterfly; affine regrouping of the costate step).
 #pragma once

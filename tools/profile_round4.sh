@@ -1,5 +1,5 @@
 #!/bin/bash
-# Run on the GPU box (through gpurun):  bash tools/profile_round4.sh
+# Run on the GPU box (through gpurun):  bash tools/profile_round4.sh [traces|counters]   (default: both halves)
 # rocprofv3 passes behind the committed profiles/r04_* summaries: the headline bench at the four per-GPU batch sizes of
 # the strong-scaling run (4096 on the wg mapping; 2048 / 1024 / 512 on the wave mapping), the instruction counters of
 # the wave kernel (its own --pmc pass: SQ_* counters, no trace domains), the in-kernel phase stamps of the wave kernel,
@@ -7,10 +7,14 @@
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"
-bash tools/profile_bench.sh r04_wg_bench || exit 1
-for b in 2048 1024 512; do
-  BENCH_ARGS="--batch $b" bash tools/profile_bench.sh r04_wave_bench_B$b || exit 1
-done
+if [ "${1:-all}" != "counters" ]; then
+  bash tools/profile_bench.sh r04_wg_bench || exit 1
+  BENCH_ARGS="--flags 128" bash tools/profile_bench.sh r04_wg_serial_bench || exit 1   # (the wg kernel with the serial state sweep)
+  for b in 2048 1024 512; do
+    BENCH_ARGS="--batch $b" bash tools/profile_bench.sh r04_wave_bench_B$b || exit 1
+  done
+fi
+[ "${1:-all}" = "traces" ] && exit 0
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES \
     --output-format csv -d "$R/gpurun_out/prof_r04_wave_sq" -- python3 "$R/bench.py" --batch 1024 --steps 100 --warmup 20 --reps 1 \
     --check-sample 0 --no-cpu-baseline --no-ref-mode > "$R/gpurun_out/prof_r04_wave_sq.json" 2> "$R/gpurun_out/prof_r04_wave_sq.err" ) || exit 1
