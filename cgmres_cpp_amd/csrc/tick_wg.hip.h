@@ -1510,7 +1510,10 @@ struct WgCtx {
   // first unperturbed sweep (preamble), which stays the serial quad sweep.  The result differs from the serial sweep's
   // by rounding only (tests/test_gpu_parity.py bounds it against the oracle like every other mapping).
   static constexpr bool ROW_NEWTON = NWT == 1;
-  static constexpr int SPL = 4, NEWTON_MAX = 8;
+  // (Newton on an explicit recurrence cannot fail to terminate: iteration n makes stage n exact — its predecessor is —
+  // so dv iterations reproduce the serial sweep whatever the start; the bound below is never reached by the test on the
+  // correction, it only has to be >= dv.  Two iterations is what the mat-vecs of a tick take.)
+  static constexpr int SPL = 4, NEWTON_MAX = 64;
   struct RowBase {
     T x0[SPL], x1[SPL], x2[SPL], sd[SPL], cd[SPL], s1[SPL], c1[SPL];
   };
