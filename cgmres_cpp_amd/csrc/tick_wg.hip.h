@@ -242,7 +242,7 @@ struct WgLds {
 // NWT = 1: the state sweeps of the Arnoldi loop run as Newton iterations on the whole trajectory, row-parallel on all
 // four waves (row_newton_sweep) instead of the serial quad sweep on wave 0; the stage table then has NWT_TABX spare
 // scalars per stage so that the 16 lanes of a row, which own four consecutive stages each, store into distinct banks.
-constexpr int NWT_TABX = 2;
+constexpr int NWT_TABX = 1;
 template <class M, class T, int IPW, int MAXM, bool LEAN = false, int PAR = 0, int NWT = 0>
 struct WgCtx {
   using Lds = WgLds<M, T, IPW, NWT ? NWT_TABX : 0>;
@@ -1573,7 +1573,8 @@ struct WgCtx {
   // may be `out`'s row: every control is read before the first result is stored).
   template <int MODE>
   __device__ __forceinline__ void row_costate(const T* x0f, const T* y1, const T* x2f, const T* y3, const T* sd, const T* cd,
-                                              const T* c1, const T* urow, T dtau, T* out, bool run, int tid_o) {
+                                              const T* c1, const T* urow, T dtau, T* out, bool run, int tid_o,
+                                              const T* u0_have = nullptr) {  // u0_have: the stages' first controls, if the caller holds them
     constexpr int NU = M::NU, NP = M::NP, NBW = M::NBW;
     static_assert(NU == 3 && NP == 2 && M::NUL == 1, "written for the pendulum's stage");
     const int r = tid_o & 15, inst = tid_o >> 4;
@@ -1597,7 +1598,8 @@ struct WgCtx {
 #pragma unroll
       for (int q = 0; q < SPL; ++q) {  // every LDS operand first (addresses clamped into the horizon: no branch, one wait)
         const int s = s_0 + q, sk = s < dv ? s : dv - 1, sp = s < dv ? s : dv;
-        u0[q] = urow[sk * NU], u1[q] = urow[sk * NU + 1], u2[q] = urow[sk * NU + 2];
+        u0[q] = u0_have ? u0_have[q] : urow[sk * NU];
+        u1[q] = urow[sk * NU + 1], u2[q] = urow[sk * NU + 2];
 #pragma unroll
         for (int j = 0; j < NP; ++j) pp[q][j] = get_p(inst, sp * NP + j);
 #pragma unroll
@@ -1609,9 +1611,11 @@ struct WgCtx {
         const T x[M::NX] = {x0f[q], y1[q], x2f[q], y3[q]};
         const T tg[3] = {sd[q], cd[q], c1[q]}, u[NU] = {u0[q], u1[q], u2[q]};
         T phi[NU], bq[NBW];
-        M::stage_coeffs(bq, phi, x, u, pp[q], tg, dtau);
+        // (with the stage's own step size: every coefficient that enters the recurrences carries it as a factor and is
+        // zero beyond the horizon; bw[3], which does not, is only used where the stage exists)
+        M::stage_coeffs(bq, phi, x, u, pp[q], tg, dq[q]);
 #pragma unroll
-        for (int cc = 0; cc < NBW; ++cc) bw[q][cc] = tr[q] ? bq[cc] : T(0);
+        for (int cc = 0; cc < NBW; ++cc) bw[q][cc] = bq[cc];
         phi0[q] = MODE == F_PLAIN ? phi[0] : (phi[0] * sc_phi - fh[q][0]) * P.inv_h;
         if (run && tr[q]) {
           out[inst * P.Lp + s * NU + 1] = MODE == F_PLAIN ? phi[1] : (phi[1] * sc_phi - fh[q][1]) * P.inv_h;
@@ -1792,6 +1796,10 @@ struct WgCtx {
       u0[q] = Wr[e];
       du[q] = tr[q] ? u0[q] - Ur[e] : T(0);
     }
+    // (the base trajectory is requested with the controls: one LDS round trip for both)
+    T b0[SPL], b2[SPL], y1[SPL], sd[SPL], cd[SPL], s1[SPL], c1[SPL];
+    load_base(0, b0, tid_o), load_base(2, b2, tid_o), load_base(1, y1, tid_o);
+    load_base(3, sd, tid_o), load_base(4, cd, tid_o), load_base(5, s1, tid_o), load_base(6, c1, tid_o);
     // ---- x0, x2: difference to the base trajectory (zero initial difference)
     const T a = T(1) - dtau * M::As, bs = dtau * M::Bs;
     T dx0[SPL], dx2[SPL];
@@ -1827,11 +1835,8 @@ struct WgCtx {
     CGM_STAMP(*this, 21);
     // ---- x1, x3: Newton.  The trig values are carried from iteration to iteration by rotation: first by the change of
     //      x0 (y1 starts at the base value), then by the corrections of y1.
-    T x0f[SPL], x2f[SPL], Pq[SPL], Qq[SPL], y1[SPL], y3[SPL], sd[SPL], cd[SPL], s1[SPL], c1[SPL];
+    T x0f[SPL], x2f[SPL], Pq[SPL], Qq[SPL], y3[SPL];
     {
-      T b0[SPL], b2[SPL];
-      load_base(0, b0, tid_o), load_base(2, b2, tid_o), load_base(1, y1, tid_o);
-      load_base(3, sd, tid_o), load_base(4, cd, tid_o), load_base(5, s1, tid_o), load_base(6, c1, tid_o);
 #pragma unroll
       for (int q = 0; q < SPL; ++q) {
         x0f[q] = b0[q] + dx0[q], x2f[q] = b2[q] + dx2[q];
@@ -1898,14 +1903,15 @@ struct WgCtx {
       for (int q = 0; q < SPL; ++q) {
         y1[q] += e1, y3[q] += e3;
         dl1[q] = e1, ad[q] = -e1, a1[q] = e1;
-        const T vq = __builtin_fmax(abs_t(e1) - th * (T(1) + abs_t(y1[q])), abs_t(e3) - th * (T(1) + abs_t(y3[q])));
+        // |e| - th (1 + |y|) > 0 ?  (the "- th" is taken off once, after the loop)
+        const T vq = __builtin_fmax(fma_t(-th, abs_t(y1[q]), abs_t(e1)), fma_t(-th, abs_t(y3[q]), abs_t(e3)));
         viol = s_0 + q <= dv ? __builtin_fmax(viol, vq) : viol;  // (beyond stage dv its correction is carried on unchanged)
         const T n1 = fma_t(dq[q], e3, e1 + c0q[q]);
         const T n3 = fma_t(eq[q], e3, fma_t(jq[q], e1, e3 + c1q[q]));
         e1 = n1, e3 = n3;
       }
       CGM_STAMP(*this, 22);
-      if (!__any(run && viol > T(0))) {
+      if (!__any(run && viol > th)) {
         // the correction is below the square root of the rounding level: trig values to first order, done
 #pragma unroll
         for (int q = 0; q < SPL; ++q) {
@@ -1917,7 +1923,7 @@ struct WgCtx {
       }
     }
     mid();
-    row_costate<MODE>(x0f, y1, x2f, y3, sd, cd, c1, Wr, dtau, out, run, tid_o);
+    row_costate<MODE>(x0f, y1, x2f, y3, sd, cd, c1, Wr, dtau, out, run, tid_o, u0);
   }
 
   // Hessenberg column k of one instance: stored reflectors, new reflector, residual rotation (gmres.hpp:71-90) — scalar
