@@ -78,7 +78,7 @@ enum {
                                           iteration that does not settle) */
   CGMRES_HIP_FLAG_SERIAL_STATE_SWEEP = 128 /* wg mapping, pendulum fp64: keep the serial state sweep on one wave in the Arnoldi
                                           loop instead of the row-parallel Newton sweeps (tick_wg.hip.h: NWT), which the
-                                          library takes where they apply (full LDS plan, 42 <= dv <= 53, k_max <= 12) */
+                                          library takes where they apply (full LDS plan, 43 <= dv <= 53, k_max <= 12) */
 };
 
 /* cgmres_hip_closed_loop_device advances up to this many consecutive ticks per kernel launch (the controller

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 U_TOL = 1e-9
 DUDT_REL = 1e-7
-# 2 = "wg" (default mapping; for the pendulum in fp64 at 42 <= dv <= 53 its row-parallel Newton sweeps, tick_wg.hip.h: NWT),
+# 2 = "wg" (default mapping; for the pendulum in fp64 at 43 <= dv <= 53 its row-parallel Newton sweeps, tick_wg.hip.h: NWT),
 # "2s" = the same with FLAG_SERIAL_STATE_SWEEP (the wg kernel with the serial quad sweep, where that differs),
 # 1 = "lane" (reference statement order), 3 = "wg-lean" (two workgroups per CU),
 # 4 = "wave" (one wavefront per controller: the latency mapping; pendulum fp64, dv <= 63, k_max <= 10)
@@ -31,8 +31,8 @@ def new_batch(*a, **kw):
     """cg.CgmresBatch; a size / model the wave mapping does not serve skips the test case."""
     if kw.get("variant") == SERIAL_STATE:
         model = a[0] if a else kw.get("model")
-        if model not in (0, "pendulum") or kw.get("dtype", "f64") != "f64" or not 42 <= kw.get("dv", 0) <= 53:
-            pytest.skip("FLAG_SERIAL_STATE_SWEEP only changes the pendulum's fp64 kernel at 42 <= dv <= 53")
+        if model not in (0, "pendulum") or kw.get("dtype", "f64") != "f64" or not 43 <= kw.get("dv", 0) <= 53:
+            pytest.skip("FLAG_SERIAL_STATE_SWEEP only changes the pendulum's fp64 kernel at 43 <= dv <= 53")
         kw = dict(kw, variant=2, flags=kw.get("flags", 0) | cg.FLAG_SERIAL_STATE_SWEEP)
     try:
         return cg.CgmresBatch(*a, **kw)
@@ -416,7 +416,7 @@ def test_chunk_parallel_costate_form_follows_the_lds_budget():
     the serial sweep on request or when not even those fit."""
     for kw, want in ((dict(model=0, dv=50, k_max=10, variant=2), "wg+row-newton"),
                      (dict(model=0, dv=50, k_max=10, variant=2, flags=cg.FLAG_SERIAL_STATE_SWEEP), "wg+parallel-costate"),
-                     (dict(model=0, dv=40, k_max=10, variant=2), "wg+parallel-costate"),  # (row-Newton: 42 <= dv <= 63)
+                     (dict(model=0, dv=40, k_max=10, variant=2), "wg+parallel-costate"),  # (row-Newton: 43 <= dv <= 53)
                      (dict(model=0, dv=50, k_max=10, variant=2, dtype="f32"), "wg+parallel-costate"),
                      (dict(model=0, dv=53, k_max=12, variant=2), "wg+two-pass-costate"),
                      (dict(model=1, dv=50, k_max=10, variant=2), "wg+two-pass-costate"),
