@@ -55,6 +55,11 @@ struct CtxWg final : cgmres_hip_ctx {
   // white-box hooks and everything else of this context stay those of the wg mapping
   bool wave = false;
   bool row_newton = false;  // wg kernel with WgCtx::NWT = 1
+  bool row_scan = false;    // wg kernel with WgCtx::NWT = 2
+  template <class MM, class = void>
+  struct RowAffine : std::false_type {};
+  template <class MM>
+  struct RowAffine<MM, std::void_t<decltype(MM::ROW_AFFINE)>> : std::integral_constant<bool, MM::ROW_AFFINE> {};
   static constexpr int kWaveKmax = 10, kWaveWpb = 1;
   size_t lds_bytes_tick() const { return wave ? WaveLds<M, T>::bytes(cfg.dv, cfg.k_max, kWaveWpb) : lds_bytes; }
   static bool wave_supported(const cgmres_hip_config& c) {
@@ -65,6 +70,7 @@ struct CtxWg final : cgmres_hip_ctx {
   const char* variant_name() const override {
     if (wave) return "wave";
     if (row_newton) return "wg+row-newton";
+    if (row_scan) return "wg+row-scan";
     static const char* const names[2][3] = {{"wg", "wg+parallel-costate", "wg+two-pass-costate"},
                                             {"wg-lean", "wg-lean", "wg-lean+two-pass-costate"}};
     return names[plan == PLAN_LEAN][par_costate];
@@ -209,6 +215,15 @@ struct CtxWg final : cgmres_hip_ctx {
     if (want == 8 && big) pick<8, 20>(false, 0);
     if constexpr (WaveOps<M>::value && std::is_same<T, double>::value) {
       if (wave) k_tick = tick_wave_kernel<M, T, kWaveKmax, kWaveWpb>;
+    }
+    // row-parallel scans for a state equation that is affine in x (WgCtx::NWT = 2): the full plan's 16-instance kernel
+    if constexpr (RowAffine<M>::value && std::is_same<T, double>::value) {
+      // (a flag that asks for a particular costate sweep asks for the kernel that has one)
+      if (!(cfg.flags & CGMRES_HIP_FLAG_SERIAL_STATE_SWEEP) && !serial && !two_pass && !wave && want == 16 && !big && !lean &&
+          !fh_hbm && cfg.dv <= 63 && cfg.k_max <= 12) {
+        row_scan = true;
+        k_tick = tick_wg_kernel<M, T, 16, 10, false, 0, 2>;
+      }
     }
     // row-parallel Newton state sweeps (WgCtx::NWT): the full plan's 16-instance kernel with the parallel costate sweep
     if constexpr (M::HAS_QUAD_SWEEP && std::is_same<T, double>::value) {

@@ -648,6 +648,7 @@ struct SemiactiveDev {
     g[2] = (u[0] - uc) * (u[0] - uc) + u[1] * u[1] - ur * ur;
   }
   static constexpr bool HAS_QUAD_SWEEP = false;
+  static constexpr bool ROW_AFFINE = true;  // dxdt is affine in x for given u: WgCtx::row_affine_sweep (tick_wg.hip.h, NWT = 2)
   static constexpr int NSLOT = NX + NC, TRIG_SLOT0 = NX, TAB_PAD = 0;
   // affine-in-costate split (model.hpp:46-55 regrouped)
   static constexpr int NBW = 4, NUL = 1, NBW_LIN = 2;  // (see PendulumDev::NBW_LIN)

@@ -1698,6 +1698,133 @@ struct WgCtx {
     CGM_STAMP(*this, 23);
   }
 
+  // ---- NWT = 2: a model whose state equation is AFFINE in x for given controls (semiactive_damper/model.hpp:36-39:
+  //      x0' = x1, x1' = a x0 + b u0 x1).  One evaluation of F (cgmres.hpp:113-162) is then two scans over the row and
+  //      nothing else — the state recurrence :132-140 as a scan of 2 x 2 maps UP the row (lane 0 starts from the constant
+  //      map "x(0)"), the costate recurrence :145-153 as one DOWN the row (the lane with stage dv starts from the terminal
+  //      costate, :143), four stages per lane folded locally on either side — exact up to rounding, no iteration, no stage
+  //      table, no serial sweep anywhere in the tick.
+  //      MODE as in row_costate; x0c: the initial state [c*IPW + i]; urow: the row of controls (may be `out`'s row).
+  template <int MODE>
+  __device__ __forceinline__ void row_affine_sweep(const T* x0c, T dtau, const T* urow, T* out, bool run) {
+    constexpr int NU = M::NU, NBW = M::NBW;
+    static_assert(M::NX == 2 && NU == 3 && M::NP == 0 && M::NUL == 1 && M::NC == 0 && NBW == 4,
+                  "written for the semi-active damper's stage");
+    int tid_o = tid;  // (see row_newton_sweep)
+    asm volatile("" : "+v"(tid_o));
+    const int r = tid_o & 15, inst = tid_o >> 4;
+    const int dv = P.dv, s_0 = SPL * r;
+    const T sc_phi = MODE == F_RHS ? P.one_m_zh : T(1.0);
+    const T sc = MODE == F_PLAIN ? T(1.0) : (MODE == F_RHS ? P.one_m_zh * P.inv_h : P.inv_h);
+    bool tr[SPL];
+    T dq[SPL], u0[SPL], u1[SPL], u2[SPL], fh[SPL][NU];
+#pragma unroll
+    for (int q = 0; q < SPL; ++q) {
+      const int s = s_0 + q, sk = s < dv ? s : dv - 1;
+      tr[q] = s < dv;
+      dq[q] = tr[q] ? dtau : T(0);  // (stages beyond the horizon: identity maps)
+      u0[q] = urow[sk * NU], u1[q] = urow[sk * NU + 1], u2[q] = urow[sk * NU + 2];
+#pragma unroll
+      for (int j = 0; j < NU; ++j) fh[q][j] = MODE == F_PLAIN ? T(0) : S.Fh[inst * P.Lp + sk * NU + j];
+    }
+    const int q_term = dv - s_0;
+    const bool has_term = q_term >= 0 && q_term < SPL, first = r == 0;
+    const T xi0 = x0c[0 * IPW + inst], xi1 = x0c[1 * IPW + inst];
+    // ---- states: x(s+1) = x(s) + [[0, dq], [dq a, dq b u0]] x(s)
+    T X0[SPL], X1[SPL], d2[SPL], d3[SPL];
+    {
+      T D[4] = {first ? T(-1) : T(0), T(0), T(0), first ? T(-1) : T(0)}, c[2] = {first ? xi0 : T(0), first ? xi1 : T(0)};
+#pragma unroll
+      for (int q = 0; q < SPL; ++q) {
+        d2[q] = dq[q] * M::a, d3[q] = dq[q] * (M::b * u0[q]);
+        const T n00 = fma_t(dq[q], D[2], D[0]);
+        const T n01 = fma_t(dq[q], D[3], D[1] + dq[q]);
+        const T n10 = fma_t(d3[q], D[2], fma_t(d2[q], D[0], D[2] + d2[q]));
+        const T n11 = fma_t(d3[q], D[3], fma_t(d2[q], D[1], D[3] + d3[q]));
+        const T m0 = fma_t(dq[q], c[1], c[0]);
+        const T m1 = fma_t(d3[q], c[1], fma_t(d2[q], c[0], c[1]));
+        D[0] = n00, D[1] = n01, D[2] = n10, D[3] = n11, c[0] = m0, c[1] = m1;
+      }
+      aff2_step_vec<0>(c, D), aff2_step_mat<0>(D);
+      aff2_step_vec<1>(c, D), aff2_step_mat<1>(D);
+      aff2_step_vec<2>(c, D), aff2_step_mat<2>(D);
+      aff2_step_vec<3>(c, D);
+      T e0 = scan_partner<0>(c[0]), e1 = scan_partner<0>(c[1]);  // the state the lane's first stage starts from
+      e0 = first ? xi0 : e0, e1 = first ? xi1 : e1;
+#pragma unroll
+      for (int q = 0; q < SPL; ++q) {
+        X0[q] = e0, X1[q] = e1;
+        const T n0 = fma_t(dq[q], e1, e0);
+        const T n1 = fma_t(d3[q], e1, fma_t(d2[q], e0, e1));
+        e0 = n0, e1 = n1;
+      }
+    }
+    // ---- stage coefficients, costate: n0 = l0 + bw2 + dq a l1,  n1 = l1 + bw3 + dq l0 + bw0 l1  (costate_step)
+    T bw[SPL][NBW], phi0[SPL], L1[SPL];
+    T lT[M::NX] = {T(0), T(0)};
+#pragma unroll
+    for (int q = 0; q < SPL; ++q) {
+      const int s = s_0 + q;
+      const T x[M::NX] = {X0[q], X1[q]}, u[NU] = {u0[q], u1[q], u2[q]};
+      T phi[NU];
+      M::stage_coeffs(bw[q], phi, x, u, nullptr, nullptr, dq[q]);  // (bw[1], which carries no step size, is only used where the stage exists)
+      phi0[q] = MODE == F_PLAIN ? phi[0] : (phi[0] * sc_phi - fh[q][0]) * P.inv_h;
+      if (run && tr[q]) {
+        out[inst * P.Lp + s * NU + 1] = MODE == F_PLAIN ? phi[1] : (phi[1] * sc_phi - fh[q][1]) * P.inv_h;
+        out[inst * P.Lp + s * NU + 2] = MODE == F_PLAIN ? phi[2] : (phi[2] * sc_phi - fh[q][2]) * P.inv_h;
+      }
+      if (q == q_term) M::dPhidx(lT, x, nullptr);
+    }
+    {
+      T D[4] = {has_term ? T(-1) : T(0), T(0), T(0), has_term ? T(-1) : T(0)};
+      T c[2] = {has_term ? lT[0] : T(0), has_term ? lT[1] : T(0)};
+#pragma unroll
+      for (int q = SPL - 1; q >= 0; --q) {
+        const T b0 = bw[q][0];
+        const T n00 = fma_t(d2[q], D[2], D[0]);
+        const T n01 = fma_t(d2[q], D[3], D[1] + d2[q]);
+        const T n10 = fma_t(b0, D[2], fma_t(dq[q], D[0], D[2] + dq[q]));
+        const T n11 = fma_t(b0, D[3], fma_t(dq[q], D[1], D[3] + b0));
+        const T m0 = fma_t(d2[q], c[1], c[0] + bw[q][2]);
+        const T m1 = fma_t(b0, c[1], fma_t(dq[q], c[0], c[1] + bw[q][3]));
+        D[0] = n00, D[1] = n01, D[2] = n10, D[3] = n11, c[0] = m0, c[1] = m1;
+      }
+      aff2_step_vec<0, true>(c, D), aff2_step_mat<0, true>(D);
+      aff2_step_vec<1, true>(c, D), aff2_step_mat<1, true>(D);
+      aff2_step_vec<2, true>(c, D), aff2_step_mat<2, true>(D);
+      aff2_step_vec<3, true>(c, D);
+      T l0 = scan_partner<0, true>(c[0]), l1 = scan_partner<0, true>(c[1]);  // costate entering the lane's last stage
+      l0 = has_term ? lT[0] : l0, l1 = has_term ? lT[1] : l1;
+#pragma unroll
+      for (int q = SPL - 1; q >= 0; --q) {
+        L1[q] = l1;
+        const T n0 = fma_t(d2[q], l1, l0 + bw[q][2]);
+        const T n1 = fma_t(bw[q][0], l1, fma_t(dq[q], l0, l1 + bw[q][3]));
+        l0 = n0, l1 = n1;
+      }
+    }
+    if (run) {
+#pragma unroll
+      for (int q = 0; q < SPL; ++q) {
+        if (tr[q]) out[inst * P.Lp + (s_0 + q) * NU] = fma_t(bw[q][1] * L1[q], sc, phi0[q]);  // B^T lambda, costate_step
+      }
+    }
+  }
+  // the preamble of a tick with it: the three evaluations of cgmres.hpp:88-99 one after the other, every row for itself
+  __device__ __forceinline__ void preamble_affine(T* bb, T* ax0) {
+    make_xh();
+    __syncthreads();  // (x + h f of every instance is formed by the sweep lanes of wave 0)
+    int tid_o = tid;
+    asm volatile("" : "+v"(tid_o));
+    const int inst = tid_o >> 4;
+    const T* Urow = S.U + inst * P.Lp;
+    row_affine_sweep<F_PLAIN>(S.xh, dtau_h, Urow, S.Fh, valid);
+    row_affine_sweep<F_AX>(S.xh, dtau_h, S.W + inst * P.Lp, S.W, valid);
+    lds_to_reg(ax0, S.W);
+    row_affine_sweep<F_RHS>(S.xs, dtau_0, Urow, S.W, valid);
+    lds_to_reg(bb, S.W);
+  }
+
   // The preamble of a tick (see preamble()) for the row-parallel kernel: the three state sweeps stay the serial quad
   // sweeps, side by side on waves 0-2 (#1 leaves its stage table in LDS, #2 / #3 park theirs in HBM); everything behind
   // them — stage coefficients, costate recurrence, dH/du — every row does for itself in registers (row_costate), one
@@ -2113,7 +2240,12 @@ struct WgCtx {
         // (the basis rows are requested between the Newton iterations and the costate scans: early enough to arrive
         // behind the scans, late enough that their registers are not live across the iterations, where the register
         // file is fullest — requested before the sweep they sit in AGPRs and every use in the rounds below is a copy)
-        row_newton_sweep<F_AX>(dtau_h, S.W, active, request_rows);  // :48  W <- A v_k, in place
+        if constexpr (NWT == 2) {
+          request_rows();  // (a light sweep: the rows may be in flight across it)
+          row_affine_sweep<F_AX>(S.xh, dtau_h, S.W + inst * P.Lp, S.W, active);
+        } else {
+          row_newton_sweep<F_AX>(dtau_h, S.W, active, request_rows);  // :48  W <- A v_k, in place
+        }
         CGM_STAMP(*this, 6);
       } else {
         ax(true, request_rows, deferred_column);  // :48  W <- A v_k, in place
@@ -2452,7 +2584,9 @@ __global__ __launch_bounds__(IPW * 16) __attribute__((amdgpu_waves_per_eu(LEAN ?
     CGM_STAMP(C, 0);
     if constexpr (!LEAN) C.publish_direction(du);  // direction of the first mat-vec: x0 = dUdt (warm start, cgmres.hpp:99)
     T ax0[MAXM];
-    if constexpr (NWT != 0) {
+    if constexpr (NWT == 2) {
+      C.preamble_affine(bb, ax0);
+    } else if constexpr (NWT == 1) {
       C.preamble_rows(bb, ax0);
       C.store_base();
     } else {

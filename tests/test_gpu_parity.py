@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 
 U_TOL = 1e-9
 DUDT_REL = 1e-7
-# 2 = "wg" (default mapping; for the pendulum in fp64 at 43 <= dv <= 53 its row-parallel Newton sweeps, tick_wg.hip.h: NWT),
+# 2 = "wg" (default mapping; in fp64 with row-parallel sweeps for the pendulum at 43 <= dv <= 53 — Newton on the trajectory —
+#     and for the semi-active damper at dv <= 53 — scans only; tick_wg.hip.h: NWT),
 # "2s" = the same with FLAG_SERIAL_STATE_SWEEP (the wg kernel with the serial quad sweep, where that differs),
 # 1 = "lane" (reference statement order), 3 = "wg-lean" (two workgroups per CU),
 # 4 = "wave" (one wavefront per controller: the latency mapping; pendulum fp64, dv <= 63, k_max <= 10)
@@ -31,8 +32,11 @@ def new_batch(*a, **kw):
     """cg.CgmresBatch; a size / model the wave mapping does not serve skips the test case."""
     if kw.get("variant") == SERIAL_STATE:
         model = a[0] if a else kw.get("model")
-        if model not in (0, "pendulum") or kw.get("dtype", "f64") != "f64" or not 43 <= kw.get("dv", 0) <= 53:
-            pytest.skip("FLAG_SERIAL_STATE_SWEEP only changes the pendulum's fp64 kernel at 43 <= dv <= 53")
+        dv = kw.get("dv", 0)
+        row_kernel = (model in (0, "pendulum") and 43 <= dv <= 53) or (model in (2, "semiactive") and dv <= 53)
+        if not row_kernel or kw.get("dtype", "f64") != "f64":
+            pytest.skip("FLAG_SERIAL_STATE_SWEEP only changes the fp64 kernels of the pendulum (43 <= dv <= 53) and the "
+                        "semi-active damper (dv <= 53)")
         kw = dict(kw, variant=2, flags=kw.get("flags", 0) | cg.FLAG_SERIAL_STATE_SWEEP)
     try:
         return cg.CgmresBatch(*a, **kw)

@@ -39,9 +39,17 @@ def test_which_handles_get_the_row_parallel_kernel():
     c = cg.CgmresBatch("pendulum", batch=4096, dv=50, k_max=10)  # the headline handle, library's choice
     assert c.variant_name == NAME
     c.close()
-    for model in ("msd", "semiactive"):
-        c = cg.CgmresBatch(model, batch=4096, dv=50 if model == "semiactive" else 26, k_max=10, variant=2)
-        assert c.variant_name != NAME
+    # the semi-active damper (state equation affine in x): scans only, "wg+row-scan"; the two-mass system: neither
+    for kw, want in ((dict(model="semiactive", dv=50, k_max=10), "wg+row-scan"), (dict(model="semiactive", dv=7, k_max=3), "wg+row-scan"),
+                     (dict(model="semiactive", dv=53, k_max=12), "wg+row-scan"),
+                     (dict(model="semiactive", dv=50, k_max=10, dtype="f32"), "wg+parallel-costate"),
+                     (dict(model="semiactive", dv=50, k_max=10, flags=cg.FLAG_SERIAL_STATE_SWEEP), "wg+parallel-costate"),
+                     (dict(model="semiactive", dv=50, k_max=10, flags=cg.FLAG_SERIAL_COSTATE), "wg"),
+                     (dict(model="msd", dv=26, k_max=10), None)):
+        args = dict(batch=4096, variant=2)
+        args.update(kw)
+        c = cg.CgmresBatch(**args)
+        assert c.variant_name == want if want else c.variant_name not in (NAME, "wg+row-scan"), (kw, c.variant_name)
         c.close()
 
 
@@ -57,6 +65,25 @@ def test_horizon_lengths_at_the_edges_of_the_stage_ownership(orc, dv, km):
         pytest.skip(f"LDS plan of dv = {dv}, k_max = {km}: {c.variant_name}")
     c.set_ptau_repeat(p), c.init_u0(u0), c.init_u0_newton(u0, x0, p, 10)
     refs = _refs(orc, 0, dv, km, 1e-6, x0, u0, p)
+    for r in refs:
+        _, U_o, d_o = r.get_state()
+        r.set_state(0.7, U_o, d_o)
+    _teacher_forced(orc, c, refs, x0, 3)
+    c.close()
+
+
+@pytest.mark.parametrize("dv,km", [(2, 2), (3, 3), (4, 4), (5, 5), (8, 4), (17, 6), (31, 10), (32, 12), (47, 7), (50, 10), (53, 12)])
+def test_row_scan_kernel_of_the_semiactive_damper_at_every_ownership_edge(orc, dv, km):
+    """"wg+row-scan" (tick_wg.hip.h: NWT = 2): the whole evaluation of F as two scans over the row — horizons from two
+    stages (one lane) up, the terminal stage in every position of its lane, ragged batch, early exits."""
+    B = 21
+    x0, u0, p = orc.batch_scenario(2, B)
+    c = cg.CgmresBatch("semiactive", batch=B, dv=dv, k_max=km, tol=1e-6, variant=2)
+    if c.variant_name != "wg+row-scan":
+        c.close()
+        pytest.skip(f"LDS plan of dv = {dv}, k_max = {km}: {c.variant_name}")
+    c.init_u0(u0), c.init_u0_newton(u0, x0, None, 10)
+    refs = _refs(orc, 2, dv, km, 1e-6, x0, u0, p)
     for r in refs:
         _, U_o, d_o = r.get_state()
         r.set_state(0.7, U_o, d_o)
