@@ -34,6 +34,8 @@
 //     state recurrence as Newton's method on the whole trajectory (four stages per lane, in-row DPP scans) and the
 //     costate recurrence as three scans down the row, all in registers, with no workgroup barrier in the loop
 //     (row_newton_sweep / row_costate); the serial state sweep remains in the preamble only.
+//     NWT = 2 (a state equation affine in x: the semi-active damper): the same with plain scans — no Newton, no serial
+//     sweep and no stage table anywhere in the tick (row_affine_sweep).
 // Statement order inside each instance follows cgmres.hpp:78-175 / gmres.hpp:28-112; what differs from the
 // reference is the association order of sums (16 partial sums + butterfly; affine regrouping of the costate step).
 #pragma once

@@ -76,9 +76,9 @@ enum {
                                           trajectory strays from the base trajectory by more than the rotation range) */
   CGMRES_HIP_FLAG_WAVE_SERIAL_SWEEPS = 64, /* wave mapping: every mat-vec takes the serial state sweep (the fall-back of a Newton
                                           iteration that does not settle) */
-  CGMRES_HIP_FLAG_SERIAL_STATE_SWEEP = 128 /* wg mapping, pendulum fp64: keep the serial state sweep on one wave in the Arnoldi
-                                          loop instead of the row-parallel Newton sweeps (tick_wg.hip.h: NWT), which the
-                                          library takes where they apply (full LDS plan, 43 <= dv <= 53, k_max <= 12) */
+  CGMRES_HIP_FLAG_SERIAL_STATE_SWEEP = 128 /* wg mapping, fp64: keep the serial state sweep in the Arnoldi loop instead of the
+                                          row-parallel sweeps (tick_wg.hip.h: NWT), which the library takes where they apply
+                                          (full LDS plan, k_max <= 12: pendulum 43 <= dv <= 53, semi-active damper dv <= 53) */
 };
 
 /* cgmres_hip_closed_loop_device advances up to this many consecutive ticks per kernel launch (the controller
@@ -151,7 +151,7 @@ int cgmres_hip_device_count(void);
 int cgmres_hip_create(const cgmres_hip_config* cfg, cgmres_hip_handle* out);
 int cgmres_hip_destroy(cgmres_hip_handle h);
 int cgmres_hip_get_config(cgmres_hip_handle h, cgmres_hip_config* cfg);
-/* Name of the mapping / kernel family the handle resolved to: "lane", "wave", "wg", "wg-lean", "wg+row-newton",
+/* Name of the mapping / kernel family the handle resolved to: "lane", "wave", "wg", "wg-lean", "wg+row-newton", "wg+row-scan",
  * "wg+parallel-costate", "wg+two-pass-costate", "wg-lean+two-pass-costate" (static
  * string; NULL on an invalid handle).  No counterpart in the reference: for logs and for tests that must know which
  * instantiation they exercised. */
