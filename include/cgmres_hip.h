@@ -72,8 +72,9 @@ enum {
   CGMRES_HIP_FLAG_NO_BINNING = 4,     /* closed loop: keep instances in caller order inside the workgroups (no k-binning) */
   CGMRES_HIP_FLAG_TWO_PASS_COSTATE = 8, /* wg mapping: the two-pass chunk-parallel costate sweep also where the LDS-scratch form fits */
   CGMRES_HIP_FLAG_NO_WAVE = 16,        /* library's choice of mapping: never the wave mapping (small batches stay on wg) */
-  CGMRES_HIP_FLAG_WAVE_FRESH_TRIG = 32, /* wave mapping: every Newton iteration evaluates sin/cos afresh (the path taken when a
-                                          trajectory strays from the base trajectory by more than the rotation range) */
+  CGMRES_HIP_FLAG_WAVE_FRESH_TRIG = 32, /* wave mapping and the row-parallel wg kernel of the pendulum: every Newton iteration
+                                          evaluates sin/cos afresh (the path taken when an angle moves by more than the
+                                          rotation range between iterations) */
   CGMRES_HIP_FLAG_WAVE_SERIAL_SWEEPS = 64, /* wave mapping: every mat-vec takes the serial state sweep (the fall-back of a Newton
                                           iteration that does not settle) */
   CGMRES_HIP_FLAG_SERIAL_STATE_SWEEP = 128 /* wg mapping, fp64: keep the serial state sweep in the Arnoldi loop instead of the
