@@ -1497,7 +1497,7 @@ struct WgCtx {
 
   // ---- NWT = 1: the perturbed state sweeps as Newton on the whole trajectory, row-parallel ----------------------------
   // The serial state sweep (sweep_state) keeps ONE wave busy for ~12 k cycles per mat-vec while the others mostly wait
-  // (profiles/r04_wg_instruction_counters.json: 23 % of the VALU issue slots used).  Here every row of 16 lanes solves its
+  // (profiles/r04_wg_serial_instruction_counters.json: 23 % of the VALU issue slots used).  Here every row of 16 lanes solves its
   // own instance's recurrence cgmres.hpp:132-140 for ALL stages at once, on all four waves:
   //   * lane r of the row owns the stages 4r .. 4r+3 (dv <= 63);
   //   * x0 / x2 (model.hpp:38,40: linear, no trig) as the DIFFERENCE to the unperturbed trajectory — a scan of the
@@ -1505,10 +1505,10 @@ struct WgCtx {
   //   * x1 / x3 by Newton's method on the stage equations, started from the unperturbed trajectory (the direction is
   //     scaled by h = 1e-3..: the perturbed trajectory is close): per iteration the stage residuals, the local
   //     composition of the lane's four linearised stage maps, one in-row scan of 2 x 2 affine maps (wave_scan.hip.h),
-  //     and the local expansion; sin / cos by rotation of the base values (fresh evaluation when an angle moved too
-  //     far).  Quadratic convergence: the loop ends when a correction is below 1e-10 relative, i.e. the next one would
+  //     and the local expansion; sin / cos carried from iteration to iteration by rotation (fresh evaluation when an
+  //     angle moved too far).  Quadratic convergence: the loop ends when a correction is below 1e-10 relative, i.e. the next one would
   //     be below rounding; measured two iterations per mat-vec.
-  // The base trajectory (x, sin/cos per owned stage: 32 values per lane) is taken from the stage table of the tick's
+  // The base trajectory (x0, x1, x2, sin/cos per owned stage: 28 values per lane) is taken from the stage table of the tick's
   // first unperturbed sweep (preamble), which stays the serial quad sweep.  The result differs from the serial sweep's
   // by rounding only (tests/test_gpu_parity.py bounds it against the oracle like every other mapping).
   static constexpr bool ROW_NEWTON = NWT == 1;
@@ -1523,8 +1523,9 @@ struct WgCtx {
   struct NoBase {};
   std::conditional_t<ROW_NEWTON, RowBase, NoBase> nb;
   mutable bool row_moved = true;  // the published direction changed at least one control of this row (publish_direction)
-  // During the Arnoldi loop the base lives in LDS — in the stage table and the costate-scan scratch, which only the
-  // preamble uses (ctx_wg checks that they are large enough) — as pairs [array][q / 2][thread]: every lane reads back
+  // During the Arnoldi loop the base lives in LDS — in the stage table, which only the preamble's state sweeps use, and
+  // in the scratch of the serial-sweep kernel's costate scan, which this kernel does not use at all (ctx_wg checks that
+  // they are large enough) — as pairs [array][q / 2][thread]: every lane reads back
   // exactly what it wrote (no barrier), 16 bytes per access, conflict-free.  Call after the preamble's last barrier.
   __device__ __forceinline__ Pair* base_pairs(int k, int thread) const {
     constexpr int PER = (SPL / 2) * IPW * 16;  // pairs per array
