@@ -55,6 +55,10 @@ struct CtxWg final : cgmres_hip_ctx {
   // white-box hooks and everything else of this context stay those of the wg mapping
   bool wave = false;
   bool row_newton = false;  // wg kernel with WgCtx::NWT = 1
+  // A Newton sweep costs the same whatever the horizon (four stages per lane, lanes beyond the horizon idle), the serial
+  // sweep is proportional to it: measured at 4096 controllers, k_max = 10 — dv = 30: 103.6 vs 100.2 us per tick (serial
+  // wins), 36: 105.3 vs 109.3, 40: 106.8 vs 114.6, 44: 99.6 vs 115.1, 50: 102.0 vs 125.1; dv = 25, k_max = 5: 59.7 vs 52.3.
+  static constexpr int kRowNewtonMinDv = 33;
   bool row_scan = false;    // wg kernel with WgCtx::NWT = 2
   template <class MM, class = void>
   struct RowAffine : std::false_type {};
@@ -225,15 +229,31 @@ struct CtxWg final : cgmres_hip_ctx {
         k_tick = tick_wg_kernel<M, T, 16, 10, false, 0, 2>;
       }
     }
-    // row-parallel Newton state sweeps (WgCtx::NWT): the full plan's 16-instance kernel with the parallel costate sweep
+    // row-parallel Newton state sweeps (WgCtx::NWT = 1): the full plan's 16-instance kernel.  Its base trajectory (NBASE
+    // arrays of 8 KB) goes where LDS is idle during the Arnoldi loop — the stage table, the scratch of the costate scan —
+    // and behind everything else for the rest; the kernel is taken when all of that fits.
     if constexpr (M::HAS_QUAD_SWEEP && std::is_same<T, double>::value) {
-      const size_t extra = size_t(cfg.dv) * NWT_TABX * sizeof(T);
-      if (!(cfg.flags & CGMRES_HIP_FLAG_SERIAL_STATE_SWEEP) && !wave && par == 1 && want == 16 && !big && !lean && !fh_hbm &&
-          cfg.dv <= 63 && cfg.k_max <= 12 && lds_bytes + extra <= kLdsLimit &&
-          // (the base trajectory of the Newton sweeps lives in the stage table and the costate-scan scratch during the loop)
-          WgLds<M, T, 16, NWT_TABX>::tab_count(cfg.dv) >= WgCtx<M, T, 16, 10, false, 1, 1>::base_tab_scalars() &&
-          WgLds<M, T, 16>::scan_count(cfg.dv) >= WgCtx<M, T, 16, 10, false, 1, 1>::base_scan_scalars()) {
-        row_newton = true, lds_bytes += extra;
+      using Ctx = WgCtx<M, T, 16, 10, false, 1, 1>;
+      using LdsX = WgLds<M, T, 16, NWT_TABX>;
+      const int Lp = L | 1, Pp = (np * (cfg.dv + 1)) | 1, Hp = pitch_H(cfg.k_max);
+      const size_t arr = Ctx::base_array_bytes();
+      auto up16 = [](size_t v) { return (v + 15) & ~size_t(15); };
+      const size_t tab_off = size_t(3) * 16 * Lp * sizeof(T), tab_cap = LdsX::tab_count(cfg.dv) * sizeof(T);
+      const size_t scan_off = up16(LdsX::count_T(cfg.dv, cfg.k_max, Lp, Pp, Hp) * sizeof(T) + 5 * 16 * sizeof(int));
+      const size_t scan_cap = par == 1 ? WgLds<M, T, 16>::scan_count(cfg.dv) * sizeof(T)
+                                       : (par == 2 ? WgLds<M, T, 16>::scan2_count(P.cs_chunks) * sizeof(T) : 0);
+      const size_t with_pad = lds_bytes + size_t(cfg.dv) * NWT_TABX * sizeof(T);
+      size_t end = up16(with_pad), off[Ctx::NBASE];
+      size_t in_tab = 0, in_scan = 0;
+      for (int k = 0; k < Ctx::NBASE; ++k) {
+        if ((in_tab + 1) * arr <= tab_cap) off[k] = tab_off + in_tab++ * arr;
+        else if ((in_scan + 1) * arr <= scan_cap) off[k] = scan_off + in_scan++ * arr;
+        else off[k] = end, end += arr;
+      }
+      if (!(cfg.flags & CGMRES_HIP_FLAG_SERIAL_STATE_SWEEP) && !serial && !two_pass && !wave && want == 16 && !big && !lean &&
+          !fh_hbm && cfg.dv >= kRowNewtonMinDv && cfg.dv <= 63 && cfg.k_max <= 12 && end <= kLdsLimit) {
+        row_newton = true, lds_bytes = end;
+        for (int k = 0; k < Ctx::NBASE; ++k) P.base_off[k] = int(off[k]);
         k_tick = tick_wg_kernel<M, T, 16, 10, false, 1, 1>;
       }
     }

@@ -61,6 +61,10 @@ struct WgParams {
   int B, dv, kmax, L, Lp, Lg, Lv, Pp, Hp, fh_hbm, lds_bytes;  // fh_hbm: F(U,x+hf,t+h) is kept in HBM only (P.Fh), see WgLds
   int wave_dbg;   // wave mapping (tick_wave.hip.h): 1 = Newton with fresh sin/cos, 2 = serial state sweep in every mat-vec
   int cs_chunks;  // chunks of the two-pass costate sweep (WgCtx::sweep_costate_2pass): 3 or 4, what the LDS budget allows
+  // row-parallel Newton kernel (WgCtx::NWT = 1): byte offsets, from the start of the workgroup's LDS, of the arrays that hold
+  // the tick's base trajectory during the Arnoldi loop (ctx_wg.hip.h places them: in the stage table and in the scratch of
+  // the chunk-parallel costate sweep, both idle then, and behind everything else where those do not suffice)
+  int base_off[8];
    // Lp/Pp/Hp: odd LDS row pitches (Hp: the COMPACT Hessenberg, column k = rows 0..k at offset k(k+1)/2; h(k+1,k) of the
    // column in progress lives in WgLds::hsub);
    // Lg: global row pitch (multiple of 16); Lv = 16*MAXM: pitch of the Krylov rows (pads kept zero, no guards)
@@ -169,6 +173,7 @@ struct WgLds {
   T *U, *Fh, *W, *R, *p, *H, *rho, *g, *xs, *xh, *xT, *u0;  // xT: terminal states of the state sweeps in flight
   T* hsub;  // h(k+1,k) of the column in progress, per instance (the compact Hessenberg keeps rows 0..k of column k only)
   T* scan;  // scratch of the chunk-parallel costate sweep (WgCtx::sweep_costate_par), full plans only
+  unsigned char* lds0;  // start of the workgroup's LDS (WgParams::base_off)
   int *flag, *reason, *nax, *ksolve;
   int* binst;  // global instance of every row of this workgroup (WgParams::perm applied)
   static __host__ __device__ size_t tab_count(int dv) {
@@ -201,6 +206,7 @@ struct WgLds {
   }
   __device__ __forceinline__ WgLds(unsigned char* base, const WgParams<T>& P, int plan) {
     T* q = reinterpret_cast<T*>(base);
+    lds0 = base;
     const int k1 = P.kmax + 1;
     const bool lean = plan == PLAN_LEAN;
     // The costate sweep's look-ahead reads up to three stages BELOW the start of its operand arrays (values never used):
@@ -1523,16 +1529,15 @@ struct WgCtx {
   struct NoBase {};
   std::conditional_t<ROW_NEWTON, RowBase, NoBase> nb;
   mutable bool row_moved = true;  // the published direction changed at least one control of this row (publish_direction)
-  // During the Arnoldi loop the base lives in LDS — in the stage table, which only the preamble's state sweeps use, and
-  // in the scratch of the serial-sweep kernel's costate scan, which this kernel does not use at all (ctx_wg checks that
-  // they are large enough) — as pairs [array][q / 2][thread]: every lane reads back
+  // During the Arnoldi loop the base lives in LDS — in the stage table, which only the preamble's state sweeps use, in
+  // the scratch of the serial-sweep kernel's costate scan, which this kernel does not use at all, and behind everything
+  // else where those two are too small (ctx_wg places the arrays: WgParams::base_off) — as pairs [q / 2][thread] per
+  // array: every lane reads back
   // exactly what it wrote (no barrier), 16 bytes per access, conflict-free.  Call after the preamble's last barrier.
   __device__ __forceinline__ Pair* base_pairs(int k, int thread) const {
-    constexpr int PER = (SPL / 2) * IPW * 16;  // pairs per array
-    return reinterpret_cast<Pair*>(k < 4 ? S.R : S.scan) + (k < 4 ? k : k - 4) * PER + thread;
+    return reinterpret_cast<Pair*>(S.lds0 + P.base_off[k]) + thread;
   }
-  static constexpr size_t base_tab_scalars() { return size_t(4) * SPL * IPW * 16; }   // needed in the stage table
-  static constexpr size_t base_scan_scalars() { return size_t(NBASE - 4) * SPL * IPW * 16; }  // and in the scan scratch
+  static constexpr size_t base_array_bytes() { return size_t(SPL) * IPW * 16 * sizeof(T); }  // one of the NBASE arrays
   __device__ __forceinline__ void store_base() {
     const T* src[NBASE] = {nb.x0, nb.x1, nb.x2, nb.sd, nb.cd, nb.s1, nb.c1};
 #pragma unroll

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 U_TOL = 1e-9
 DUDT_REL = 1e-7
-# 2 = "wg" (default mapping; in fp64 with row-parallel sweeps for the pendulum at 43 <= dv <= 53 — Newton on the trajectory —
+# 2 = "wg" (default mapping; in fp64 with row-parallel sweeps for the pendulum at 33 <= dv <= 53 — Newton on the trajectory —
 #     and for the semi-active damper at dv <= 53 — scans only; tick_wg.hip.h: NWT),
 # "2s" = the same with FLAG_SERIAL_STATE_SWEEP (the wg kernel with the serial quad sweep, where that differs),
 # 1 = "lane" (reference statement order), 3 = "wg-lean" (two workgroups per CU),
@@ -33,10 +33,10 @@ def new_batch(*a, **kw):
     if kw.get("variant") == SERIAL_STATE:
         model = a[0] if a else kw.get("model")
         dv = kw.get("dv", 0)
-        row_kernel = (model in (0, "pendulum") and 43 <= dv <= 53) or (model in (2, "semiactive") and dv <= 53)
+        row_kernel = (model in (0, "pendulum") and 33 <= dv <= 53) or (model in (2, "semiactive") and dv <= 53)
         if not row_kernel or kw.get("dtype", "f64") != "f64":
-            pytest.skip("FLAG_SERIAL_STATE_SWEEP only changes the fp64 kernels of the pendulum (43 <= dv <= 53) and the "
-                        "semi-active damper (dv <= 53)")
+            pytest.skip("FLAG_SERIAL_STATE_SWEEP only changes the fp64 kernels of the pendulum and the semi-active damper "
+                        "at dim_u*dv <= 160")
         kw = dict(kw, variant=2, flags=kw.get("flags", 0) | cg.FLAG_SERIAL_STATE_SWEEP)
     try:
         return cg.CgmresBatch(*a, **kw)
@@ -420,9 +420,12 @@ def test_chunk_parallel_costate_form_follows_the_lds_budget():
     the serial sweep on request or when not even those fit."""
     for kw, want in ((dict(model=0, dv=50, k_max=10, variant=2), "wg+row-newton"),
                      (dict(model=0, dv=50, k_max=10, variant=2, flags=cg.FLAG_SERIAL_STATE_SWEEP), "wg+parallel-costate"),
-                     (dict(model=0, dv=40, k_max=10, variant=2), "wg+parallel-costate"),  # (row-Newton: 43 <= dv <= 53)
+                     (dict(model=0, dv=40, k_max=10, variant=2), "wg+row-newton"),
+                     (dict(model=0, dv=54, k_max=10, variant=2), "wg+two-pass-costate"),  # (dim_u*dv > 160: the long-vector kernels)
                      (dict(model=0, dv=50, k_max=10, variant=2, dtype="f32"), "wg+parallel-costate"),
-                     (dict(model=0, dv=53, k_max=12, variant=2), "wg+two-pass-costate"),
+                     (dict(model=0, dv=53, k_max=12, variant=2), "wg+row-newton"),
+                     (dict(model=0, dv=53, k_max=12, variant=2, flags=cg.FLAG_SERIAL_STATE_SWEEP), "wg+two-pass-costate"),
+                     (dict(model=0, dv=30, k_max=10, variant=2), "wg+parallel-costate"),  # (short horizons: the serial sweep is cheaper)
                      (dict(model=1, dv=50, k_max=10, variant=2), "wg+two-pass-costate"),
                      (dict(model=0, dv=50, k_max=10, variant=3), "wg-lean+two-pass-costate"),
                      (dict(model=0, dv=100, k_max=20, variant=3, dtype="f32"), "wg-lean+two-pass-costate"),

@@ -24,8 +24,8 @@ def _batch(B, dv, km, tol, flags=0):
 
 def test_which_handles_get_the_row_parallel_kernel():
     for kw, want in ((dict(dv=50, k_max=10), True), (dict(dv=43, k_max=5), True), (dict(dv=53, k_max=8), True),
-                     (dict(dv=44, k_max=12), True),
-                     (dict(dv=42, k_max=10), False),                       # base trajectory does not fit the stage table
+                     (dict(dv=44, k_max=12), True), (dict(dv=42, k_max=10), True), (dict(dv=33, k_max=10), True),
+                     (dict(dv=32, k_max=10), False), (dict(dv=25, k_max=5), False),  # short horizons: the serial sweep is cheaper
                      (dict(dv=54, k_max=10), False),                       # dim_u*dv > 160: the long-vector kernels
                      (dict(dv=50, k_max=10, dtype="f32"), False),
                      (dict(dv=50, k_max=10, flags=cg.FLAG_SERIAL_STATE_SWEEP), False),
@@ -53,10 +53,12 @@ def test_which_handles_get_the_row_parallel_kernel():
         c.close()
 
 
-@pytest.mark.parametrize("dv,km", [(43, 3), (44, 12), (46, 10), (45, 6), (47, 7), (48, 9), (49, 10), (51, 4), (52, 10), (53, 8)])
+@pytest.mark.parametrize("dv,km", [(33, 10), (34, 4), (35, 6), (36, 12), (39, 8), (42, 10),
+                                    (43, 3), (44, 12), (46, 10), (45, 6), (47, 7), (48, 9), (49, 10), (51, 4), (52, 10), (53, 8)])
 def test_horizon_lengths_at_the_edges_of_the_stage_ownership(orc, dv, km):
     """Lane r of a row owns stages 4r..4r+3 and the terminal state sits at "stage dv": horizons whose last stage is the
-    first, second, third and fourth stage of its lane, the shortest (43) and the longest (53) the kernel takes."""
+    first, second, third and fourth stage of its lane, from the shortest horizon the library gives this kernel (33: part
+    of the base trajectory in an LDS region of its own) to the longest (53)."""
     B = 21
     x0, u0, p = orc.batch_scenario(0, B)
     c = _batch(B, dv, km, 1e-6)
