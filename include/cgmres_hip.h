@@ -79,7 +79,7 @@ enum {
                                           iteration that does not settle) */
   CGMRES_HIP_FLAG_SERIAL_STATE_SWEEP = 128 /* wg mapping, fp64: keep the serial state sweep in the Arnoldi loop instead of the
                                           row-parallel sweeps (tick_wg.hip.h: NWT), which the library takes where they apply
-                                          (full LDS plan, k_max <= 12: pendulum 43 <= dv <= 53, semi-active damper dv <= 53) */
+                                          (full LDS plan, k_max <= 12: pendulum 33 <= dv <= 53, semi-active damper dv <= 53) */
 };
 
 /* cgmres_hip_closed_loop_device advances up to this many consecutive ticks per kernel launch (the controller
