@@ -2189,6 +2189,15 @@ struct WgCtx {
     int k = 0;
     for (; k < kmax; ++k) {  // gmres.hpp:46
       CGM_STAMP(*this, 14);
+      if constexpr (LEAN || NWT != 0 || MAXM > 10) {
+        // Whatever derives from the thread index alone is invariant over the whole launch, gets hoisted to the kernel
+        // entry and — there being no room in these kernels — spilled; its reloads inside the iteration sit behind
+        // s_waitcnt vmcnt(0), i.e. wait for the basis rows in flight.  Opaque copies once per iteration: the few integer
+        // operations are redone instead.  (Spilled VGPRs: lean pendulum fp64 91 -> 2, lean two-mass system 81 -> 0,
+        // lean pendulum fp32 k = 20 86 -> 0, the row-parallel kernel 108 -> 0 and 103.6 -> 99.8 us per tick; the
+        // short-vector serial-sweep kernels have next to none to lose and are 1 % slower with it: left alone.)
+        asm volatile("" : "+v"(tid), "+v"(inst), "+v"(r), "+v"(b));
+      }
       if constexpr (NWT != 0) {
         // Row-parallel sweeps: everything an iteration touches in LDS — the row of W, the row's small Krylov arrays —
         // is written and read by the 16 lanes of ONE row, i.e. inside one wave, whose LDS operations complete in
